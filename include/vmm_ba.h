@@ -1,0 +1,215 @@
+/*
+ * vmm_ba.h -- C-ABI of libvmm_ba.so: the MI355X (gfx950) bundle-adjustment engine behind
+ * visual_marker_mapping's TagReconstructor hot path.
+ *
+ * Plain C: pointers and sizes only, no Eigen/torch types.  Each entry point names the reference
+ * interface it replaces (file:line relative to /root/reference).  Host arrays are owned by the
+ * caller; the handle owns device memory; nothing is thrown across this boundary -- every call
+ * returns a status and vmm_ba_last_error() holds the text of the last failure on this thread.
+ *
+ * Data conventions (reference: include/visual_marker_mapping/Camera.h:13-17,
+ * TagReconstructor.h:19-52, DetectionResults.h:10-37):
+ *   pose      = 7 doubles: quaternion (w,x,y,z), translation (x,y,z)
+ *   camera    = world->camera, tag = tag->world (TagReconstructionCostFunction.h:107-122)
+ *   tag quad  = LL,LR,UR,UL = (-w/2,-h/2,0),(w/2,-h/2,0),(w/2,h/2,0),(-w/2,h/2,0)
+ *   obs_px    = 8 doubles per tag observation: the four corners' (u,v) in that order
+ *   tangent   = 6 per pose: translation(3), then the half-angle rotation vector(3) of
+ *               ceres::QuaternionParameterization (src/TagReconstructor.cpp:661)
+ */
+#ifndef VMM_BA_H_
+#define VMM_BA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMM_BA_ABI_VERSION 1
+
+typedef struct vmm_ba_handle_s* vmm_ba_handle;
+
+/* status codes */
+enum {
+    VMM_BA_OK = 0,
+    VMM_BA_ERR_ARGUMENT = 1,   /* bad sizes / indices / null pointers */
+    VMM_BA_ERR_HIP = 2,        /* a HIP runtime call failed (no device, OOM, launch failure) */
+    VMM_BA_ERR_COLLECTIVE = 3, /* the user-supplied all-reduce callback reported failure */
+    VMM_BA_ERR_STATE = 4       /* call sequence error */
+};
+
+/* which pose family is eliminated by block Gaussian elimination before the dense reduced solve.
+ * The reference puts tags in Ceres ordering group 0 and cameras in group 1
+ * (src/TagReconstructor.cpp:675-676,695-696) but keeps Ceres' default exact solver; any exact
+ * elimination yields the same LM step. */
+enum {
+    VMM_BA_ELIM_AUTO = 0,    /* eliminate the larger family -> smaller reduced system */
+    VMM_BA_ELIM_TAGS = 1,    /* reduced camera system (the reference's ordering) */
+    VMM_BA_ELIM_CAMERAS = 2  /* reduced tag system */
+};
+
+/* Ceres termination_type as printed by src/TagReconstructor.cpp:740 */
+enum { VMM_BA_CONVERGENCE = 0, VMM_BA_NO_CONVERGENCE = 1, VMM_BA_FAILURE = 2 };
+
+/* The problem TagReconstructor::doBundleAdjustment assembles at src/TagReconstructor.cpp:646-724:
+ * reconstructed tags, reconstructed cameras with >= 1 reconstructed tag, and the observations
+ * whose camera and tag are both reconstructed, with dense 0-based indices. */
+typedef struct vmm_ba_problem {
+    double intr[4];          /* fx, fy, cx, cy           CameraModel.h:14-17 */
+    double dist[5];          /* k1, k2, p1, p2, k3       CameraModel.cpp:11-16 */
+    int32_t n_cams;
+    int32_t n_tags;
+    const double* cam_qt;    /* [7*n_cams] initial camera poses (src/TagReconstructor.cpp:692-693) */
+    const double* tag_qt;    /* [7*n_tags] initial tag poses    (src/TagReconstructor.cpp:665-666) */
+    const double* tag_wh;    /* [2*n_tags] tag width, height    (src/TagReconstructor.cpp:713,718) */
+    int32_t fixed_tag;       /* dense index of the origin tag, or -1 (src/TagReconstructor.cpp:669-673) */
+    int64_t n_obs;
+    const int32_t* obs_cam;  /* [n_obs] */
+    const int32_t* obs_tag;  /* [n_obs] */
+    const double* obs_px;    /* [8*n_obs] (src/DetectionIO.cpp:45-51) */
+} vmm_ba_problem;
+
+typedef struct vmm_ba_create_options {
+    int32_t device;          /* HIP device ordinal */
+    int32_t elimination;     /* VMM_BA_ELIM_* */
+    /* Multi-GPU: one process per GPU.  Every rank passes ALL poses and only ITS shard of the
+     * observations (sharded by the eliminated family, cameras by default); rank/world are
+     * informational, the exchange itself goes through vmm_ba_set_allreduce(). */
+    int32_t rank;
+    int32_t world_size;
+} vmm_ba_create_options;
+
+/* Solver::Options fields the reference sets (src/TagReconstructor.cpp:725-735) plus the Ceres
+ * defaults that are in force because it does not set them. */
+typedef struct vmm_ba_options {
+    int32_t max_num_iterations;        /* 400 / 1500: src/TagReconstructor.cpp:233,271,277 */
+    int32_t robustify;                 /* HuberLoss(huber_a) per corner block, :721 */
+    double huber_a;                    /* 1.0 */
+    double function_tolerance;         /* 1e-6  */
+    double gradient_tolerance;         /* 1e-10 */
+    double parameter_tolerance;        /* 1e-8  */
+    double initial_trust_region_radius;/* 1e4   */
+    double max_trust_region_radius;    /* 1e16  */
+    double min_trust_region_radius;    /* 1e-32 */
+    double min_relative_decrease;      /* 1e-3  */
+    double min_lm_diagonal;            /* 1e-6  */
+    double max_lm_diagonal;            /* 1e32  */
+    int32_t max_num_consecutive_invalid_steps; /* 5 */
+    int32_t jacobi_scaling;            /* 1 */
+    int32_t num_threads;               /* accepted for signature parity (:733); the GPU path ignores it */
+    int32_t poll_interval;             /* LM iterations enqueued between host polls of the device
+                                          control block (>=1); does not change results */
+} vmm_ba_options;
+
+/* One row of Ceres' Solver::Summary::iterations. */
+typedef struct vmm_ba_iteration {
+    int32_t iteration;
+    int32_t step_is_valid;
+    int32_t step_is_successful;
+    int32_t reserved;
+    double cost;
+    double cost_change;
+    double gradient_max_norm;
+    double step_norm;
+    double relative_decrease;
+    double trust_region_radius;
+    double model_cost_change;
+} vmm_ba_iteration;
+
+typedef struct vmm_ba_summary {
+    int32_t termination_type;       /* VMM_BA_CONVERGENCE / NO_CONVERGENCE / FAILURE */
+    int32_t iterations;             /* == Ceres summary.iterations.size() */
+    int32_t num_successful_steps;
+    int32_t num_unsuccessful_steps;
+    int32_t num_lm_iterations;      /* passes of the trust-region loop (each = 1 linear solve) */
+    int32_t num_jacobian_evals;
+    int32_t num_cost_evals;
+    int32_t elimination;            /* the VMM_BA_ELIM_* actually used */
+    double initial_cost;
+    double final_cost;
+    double time_solve_s;            /* host wall time of vmm_ba_solve */
+    vmm_ba_iteration* trace;        /* optional caller buffer, filled up to trace_capacity rows */
+    int32_t trace_capacity;
+    int32_t reserved;
+} vmm_ba_summary;
+
+/* Sum-all-reduce of `count` doubles in DEVICE memory, in place, ordered on `hip_stream`
+ * (a hipStream_t).  Return 0 on success.  Called by vmm_ba_solve / vmm_ba_cost on every rank in
+ * the same order.  The default (none set) is the single-GPU identity. */
+typedef int (*vmm_ba_allreduce_fn)(void* user, void* device_buffer, size_t count, void* hip_stream);
+
+/* Average duration of each device kernel of one LM iteration, measured with HIP events on the
+ * engine's own stream (bench.py's roofline leg). */
+typedef struct vmm_ba_kernel_times {
+    double eval_elim_ms;     /* residual+Jacobian+accumulate pass ordered by the eliminated family (writes W) */
+    double eval_keep_ms;     /* the same pass ordered by the kept family */
+    double cost_ms;          /* cost-only residual pass */
+    double form_z_ms;        /* block factor + Z = L^-1 W */
+    double syrk_ms;          /* reduced system: S -= Z^T Z (f64 MFMA) */
+    double cholesky_ms;      /* dense Cholesky + triangular solves of the reduced system */
+    double backsub_ms;       /* back-substitution + Plus + model cost */
+    double lm_iteration_ms;  /* one whole LM iteration as enqueued by vmm_ba_solve */
+    int64_t n_obs;
+    int32_t reduced_dim;     /* order of the dense reduced system (without padding) */
+    int32_t elim_dim;        /* 6 * number of eliminated poses */
+} vmm_ba_kernel_times;
+
+const char* vmm_ba_last_error(void);
+int vmm_ba_abi_version(void);
+void vmm_ba_default_options(vmm_ba_options* o);
+void vmm_ba_default_create_options(vmm_ba_create_options* o);
+
+/* Replaces the ceres::Problem construction of src/TagReconstructor.cpp:657-724: uploads poses and
+ * observations, sorts them by pose family, builds the block structure.  Done once per problem. */
+int vmm_ba_create(const vmm_ba_problem* problem, const vmm_ba_create_options* copt,
+                  vmm_ba_handle* out);
+void vmm_ba_destroy(vmm_ba_handle h);
+
+/* Poses live on the device between calls (the reference mutates map nodes in place through raw
+ * double*, src/TagReconstructor.cpp:665-666,692-693,722). */
+int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt);
+int vmm_ba_get_state(vmm_ba_handle h, double* cam_qt, double* tag_qt);
+
+int vmm_ba_set_allreduce(vmm_ba_handle h, vmm_ba_allreduce_fn fn, void* user);
+
+/* Replaces ceres::Solve at src/TagReconstructor.cpp:737-738. */
+int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* summary);
+
+/* Cost-only evaluation 1/2 sum rho(|r|^2) at the current state (Ceres Evaluator, cost only). */
+int vmm_ba_cost(vmm_ba_handle h, int robustify, double huber_a, double* cost);
+
+/* Replaces computeReprojectionErrorPerImg / PerTag / PerCorner (src/TagReconstructor.cpp:340-455):
+ * per_cam_mean[n_cams] (-1 for a camera without observations, :379-383), per_tag_mean[n_tags]
+ * (NaN for a tag without observations), *avg (:416-426), per_corner[8*n_obs] signed pixel errors in
+ * the caller's observation order (:447-451).  Any output may be NULL. */
+int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per_tag_mean,
+                              double* avg, double* per_corner);
+
+/* Replaces CameraModel::projectPoint (src/CameraModel.cpp:6-26) for n camera-frame points. */
+int vmm_ba_project_points(const double intr[4], const double dist[5], int64_t n,
+                          const double* points_cam, double* uv, int device);
+
+/* Test/diagnostic: one residual+Jacobian evaluation at the current state; copies out the
+ * accumulated normal-equation blocks in the caller's index space.  Any output may be NULL.
+ *   V[36*n_cams], U[36*n_tags]  row-major 6x6 J^T J diagonal blocks (Huber-corrected, unscaled)
+ *   W[36*n_obs]                 row-major 6x6 J_cam^T J_tag per observation, caller's order
+ *   g_cam[6*n_cams], g_tag[6*n_tags]  J^T r                                               */
+int vmm_ba_eval_blocks(vmm_ba_handle h, int robustify, double huber_a, double* cost, double* V,
+                       double* U, double* W, double* g_cam, double* g_tag);
+
+/* Test/diagnostic: solves A x = b for a dense SPD A (row-major n x n, host memory) with the
+ * engine's blocked Cholesky and triangular solves; reports failure through *info != 0. */
+int vmm_ba_dense_spd_solve(int device, int n, const double* A, const double* b, double* x, int* info);
+
+/* Test/diagnostic: C = Z^T Z (n x n, row-major, lower triangle valid) for a row-major k x n Z with
+ * the engine's MFMA kernel. */
+int vmm_ba_dense_syrk(int device, int k, int n, const double* Z, double* C);
+
+/* Times each kernel of an LM iteration at the current state (reps launches each). */
+int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vmm_ba_kernel_times* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,136 @@
+"""GPU unit tests of the individual HIP kernels, called through the C-ABI (include/vmm_ba.h).
+
+Run on the MI355X box with `pytest -m gpu`.  The checker is the CPU oracle (oracle/) or numpy; the
+HIP path itself never touches either.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from visual_marker_mapping_amd import engine
+    return engine
+
+
+def _blocks_from_oracle(O, s, cam, tag, robustify):
+    """V, U, W, g, cost from the oracle's per-observation residuals/Jacobians (numpy accumulation)."""
+    n_c, n_t = len(cam), len(tag)
+    V, U = np.zeros((n_c, 6, 6)), np.zeros((n_t, 6, 6))
+    W = np.zeros((len(s.obs_cam), 6, 6))
+    gc, gt = np.zeros((n_c, 6)), np.zeros((n_t, 6))
+    cost = 0.0
+    for i, (c, t) in enumerate(zip(s.obs_cam, s.obs_tag)):
+        r, Jc, Jt = O.obs_eval(s.intr, s.dist, cam[c], tag[t], s.tag_wh[t], s.obs_px[i])
+        if t == s.fixed_tag:
+            Jt = np.zeros_like(Jt)
+        for k in range(4):
+            sq = r[2 * k] ** 2 + r[2 * k + 1] ** 2
+            rho = O.huber(1.0, sq) if robustify else np.array([sq, 1.0, 0.0])
+            cost += 0.5 * rho[0]
+            w = np.sqrt(rho[1])
+            Jc[2 * k:2 * k + 2] *= w
+            Jt[2 * k:2 * k + 2] *= w
+            r[2 * k:2 * k + 2] *= w
+        V[c] += Jc.T @ Jc
+        U[t] += Jt.T @ Jt
+        W[i] = Jc.T @ Jt
+        gc[c] += Jc.T @ r
+        gt[t] += Jt.T @ r
+    return dict(V=V, U=U, W=W, g_cam=gc, g_tag=gt, cost=cost)
+
+
+def test_mfma_f64_syrk_matches_numpy(eng):
+    rng = np.random.default_rng(1)
+    for k, n in [(16, 64), (100, 130), (600, 200), (37, 65)]:
+        Z = rng.standard_normal((k, n))
+        # asymmetric, integer-valued data also catches a transposed C/D lane map exactly
+        Zi = np.round(Z * 3.0)
+        for M in (Z, Zi):
+            Cg = eng.dense_syrk(M)
+            ref = M.T @ M
+            np.testing.assert_allclose(Cg, ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max()))
+
+
+def test_blocked_cholesky_solve_matches_numpy(eng):
+    rng = np.random.default_rng(2)
+    for n in (5, 64, 65, 200, 333, 1200):
+        B = rng.standard_normal((n, n))
+        A = B @ B.T + n * np.eye(n)
+        b = rng.standard_normal(n)
+        x, info = eng.dense_spd_solve(A, b)
+        assert info == 0
+        ref = np.linalg.solve(A, b)
+        np.testing.assert_allclose(x, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+
+
+def test_cholesky_reports_indefinite_matrix(eng):
+    A = np.eye(70)
+    A[50, 50] = -1.0
+    _, info = eng.dense_spd_solve(A, np.ones(70))
+    assert info != 0
+
+
+def test_project_points_matches_oracle(eng, oracle, kats):
+    rng = np.random.default_rng(3)
+    pts = np.c_[rng.uniform(-1, 1, 50), rng.uniform(-1, 1, 50), rng.uniform(1.5, 4, 50)]
+    for case in kats["obs"][:2]:
+        uv = eng.project_points(case["intr"], case["dist"], pts)
+        ref = np.array([oracle.project_point(case["intr"], case["dist"], p) for p in pts])
+        np.testing.assert_allclose(uv, ref, rtol=0, atol=1e-9)
+
+
+def test_residual_and_jacobian_kats_through_the_engine(eng, kats):
+    """One camera, one tag, one observation: the accumulated blocks are J^T J of the mpmath KAT."""
+    for case in kats["obs"]:
+        ba = eng.BundleAdjuster(case["intr"], case["dist"], [case["cam_qt"]], [case["tag_qt"]], [case["wh"]],
+                                -1, [0], [0], [case["px"]])
+        r = np.array(case["residual"])
+        Jc, Jt = np.array(case["J_cam"]), np.array(case["J_tag"])
+        assert abs(ba.cost(robustify=False) - 0.5 * r @ r) <= 1e-12 * (0.5 * r @ r)
+        blk = ba.eval_blocks(robustify=False)
+        for got, ref in ((blk["V"][0], Jc.T @ Jc), (blk["U"][0], Jt.T @ Jt), (blk["W"][0], Jc.T @ Jt),
+                         (blk["g_cam"][0], Jc.T @ r), (blk["g_tag"][0], Jt.T @ r)):
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+        ba.close()
+
+
+@pytest.mark.parametrize("elim", ["cams", "tags"])
+@pytest.mark.parametrize("robust", [False, True])
+def test_accumulated_blocks_match_oracle(eng, oracle, elim, robust):
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(5, n_cams=7, n_tags=5)   # distortion + outliers
+    mode = eng.ELIM_CAMERAS if elim == "cams" else eng.ELIM_TAGS
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam,
+                            s.obs_tag, s.obs_px, elimination=mode)
+    ref = _blocks_from_oracle(oracle, s, s.cam_init, s.tag_init, robust)
+    got = ba.eval_blocks(robustify=robust)
+    assert abs(got["cost"] - ref["cost"]) <= 1e-11 * ref["cost"]
+    for k in ("V", "U", "W", "g_cam", "g_tag"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=0, atol=1e-10 * np.abs(ref[k]).max(), err_msg=k)
+    assert abs(ba.cost(robustify=robust) - ref["cost"]) <= 1e-11 * ref["cost"]
+    ba.close()
+
+
+def test_reprojection_statistics_match_oracle(eng, oracle):
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, visibility=0.5)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam,
+                            s.obs_tag, s.obs_px)
+    sc = oracle.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px)
+    pc, pt, avg, corner = oracle.reprojection_stats(sc)
+    gc, gt, gavg, gcorner = ba.reprojection_stats()
+    np.testing.assert_allclose(gcorner, corner, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gc, pc, rtol=1e-12)
+    np.testing.assert_allclose(gt, pt, rtol=1e-12)
+    assert abs(gavg - avg) <= 1e-12 * avg
+    ba.close()
+
+
+def test_bad_indices_are_rejected(eng):
+    from visual_marker_mapping_amd import _lib
+    with pytest.raises(_lib.VmmBaError):
+        eng.BundleAdjuster([1, 1, 0, 0], [0] * 5, [[1, 0, 0, 0, 0, 0, 1]], [[1, 0, 0, 0, 0, 0, 0]], [[0.1, 0.1]],
+                           0, [3], [0], [[0] * 8])

@@ -1,0 +1,156 @@
+"""GPU parity tests of the whole hot path (vmm_ba_solve) against the CPU oracle.
+
+north_star tolerance: converged poses / marker corners within 1e-6 relative of the reference
+semantics on the same detections.  The oracle restates Ceres' trust-region policy (PARITY UNPINNED
+against Ceres itself, see oracle/vmm_oracle.h), so beyond the end state the whole iteration trace is
+compared.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6  # north_star: "within 1e-6 relative"
+
+
+def _run_both(eng, O, s, elim, **opt):
+    mode = {"auto": eng.ELIM_AUTO, "cams": eng.ELIM_CAMERAS, "tags": eng.ELIM_TAGS}[elim]
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam,
+                            s.obs_tag, s.obs_px, elimination=mode)
+    out = ba.solve(eng.default_options(**opt), trace_capacity=256)
+    cam, tag = ba.get_state()
+    ba.close()
+    sc = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+    oopt = {k: v for k, v in opt.items() if k != "poll_interval"}
+    summ, trace = O.solve(sc, O.default_options(linear_solver=O.DENSE_NORMAL if len(s.cam_gt) <= 40 else O.SCHUR_AUTO,
+                                                **oopt))
+    return out, cam, tag, summ, trace, sc
+
+
+def _world_corners(qt, wh):
+    q = qt[:, :4] / np.linalg.norm(qt[:, :4], axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                  2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                  2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+    out = []
+    for sx, sy in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+        p = np.stack([sx * wh[:, 0] / 2, sy * wh[:, 1] / 2, np.zeros(len(wh))], axis=1)
+        out.append(np.einsum("nij,nj->ni", R, p) + qt[:, 4:])
+    return np.stack(out, axis=1)
+
+
+def _assert_same_solution(cam, tag, sc, wh):
+    scale = max(np.abs(sc.cam_qt).max(), np.abs(sc.tag_qt).max())
+    np.testing.assert_allclose(cam, sc.cam_qt, rtol=0, atol=REL * scale)
+    np.testing.assert_allclose(tag, sc.tag_qt, rtol=0, atol=REL * scale)
+    a, b = _world_corners(tag, wh), _world_corners(sc.tag_qt, wh)
+    np.testing.assert_allclose(a, b, rtol=0, atol=REL * np.abs(b).max())
+
+
+def _assert_same_trace(out, summ, trace, rtol=1e-7):
+    assert out["termination_type"] == summ["termination_type"]
+    assert out["iterations"] == summ["iterations"]
+    assert out["num_successful_steps"] == summ["num_successful_steps"]
+    assert out["num_unsuccessful_steps"] == summ["num_unsuccessful_steps"]
+    for a, b in zip(out["trace"], trace):
+        assert a["iteration"] == b["iteration"]
+        assert a["step_is_successful"] == b["step_is_successful"]
+        np.testing.assert_allclose(a["cost"], b["cost"], rtol=rtol)
+        np.testing.assert_allclose(a["trust_region_radius"], b["trust_region_radius"], rtol=1e-5)
+    np.testing.assert_allclose(out["final_cost"], summ["final_cost"], rtol=rtol)
+    np.testing.assert_allclose(out["initial_cost"], summ["initial_cost"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("elim", ["cams", "tags"])
+@pytest.mark.parametrize("robust", [0, 1])
+def test_config1_matches_oracle(oracle, elim, robust):
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1)  # BASELINE.json configs[0]: 20 images x 10 tags
+    out, cam, tag, summ, trace, sc = _run_both(eng, oracle, s, elim, robustify=robust)
+    _assert_same_trace(out, summ, trace)
+    _assert_same_solution(cam, tag, sc, s.tag_wh)
+
+
+def test_distortion_outliers_robust_matches_oracle(oracle):
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(5, n_cams=30, n_tags=12)  # configs[4] shape at a size the dense oracle solves fast
+    out, cam, tag, summ, trace, sc = _run_both(eng, oracle, s, "auto", robustify=1)
+    _assert_same_trace(out, summ, trace)
+    _assert_same_solution(cam, tag, sc, s.tag_wh)
+
+
+def test_sparse_visibility_matches_oracle(oracle):
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=40, n_tags=30, visibility=0.25)
+    out, cam, tag, summ, trace, sc = _run_both(eng, oracle, s, "auto", robustify=1)
+    _assert_same_trace(out, summ, trace)
+    _assert_same_solution(cam, tag, sc, s.tag_wh)
+
+
+def test_zero_noise_scene_recovers_ground_truth():
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, noise_px=0.0)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam,
+                            s.obs_tag, s.obs_px)
+    out = ba.solve(eng.default_options(robustify=0, function_tolerance=1e-16, parameter_tolerance=1e-14,
+                                       max_num_iterations=50))
+    cam, tag = ba.get_state()
+    ba.close()
+    assert out["final_cost"] < 1e-10
+    for got, gt in ((cam, s.cam_gt), (tag, s.tag_gt)):
+        sign = np.sign(np.sum(got[:, :4] * gt[:, :4], axis=1))[:, None]
+        np.testing.assert_allclose(got[:, :4] * sign, gt[:, :4], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(got[:, 4:], gt[:, 4:], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(tag[0], s.tag_init[0])  # origin tag constant
+
+
+def test_iteration_cap_and_polling_do_not_change_results():
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1)
+    res = []
+    for poll in (1, 4):
+        ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam,
+                                s.obs_tag, s.obs_px)
+        out = ba.solve(eng.default_options(poll_interval=poll), trace_capacity=64)
+        res.append((out, ba.get_state()))
+        capped = None
+        ba.set_state(s.cam_init, s.tag_init)
+        capped = ba.solve(eng.default_options(max_num_iterations=2, poll_interval=poll))
+        assert capped["termination_type"] == eng.NO_CONVERGENCE and capped["iterations"] == 3
+        ba.close()
+    assert res[0][0]["iterations"] == res[1][0]["iterations"]
+    np.testing.assert_array_equal(res[0][1][0], res[1][1][0])
+    np.testing.assert_array_equal(res[0][1][1], res[1][1][1])
+
+
+@pytest.mark.parametrize("cfg", [2])
+def test_full_size_config2_properties(oracle, cfg):
+    """BASELINE.json configs[1] (500 x 200, f64): trace parity with the oracle's Schur path plus
+    size-independent properties (cost decreases monotonically, origin fixed, unit quaternions)."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(cfg)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam,
+                            s.obs_tag, s.obs_px)
+    out = ba.solve(eng.default_options(robustify=0), trace_capacity=64)
+    cam, tag = ba.get_state()
+    ba.close()
+    costs = [t["cost"] for t in out["trace"] if t["step_is_successful"]]
+    assert all(b < a for a, b in zip(costs, costs[1:]))
+    assert out["termination_type"] == eng.CONVERGENCE
+    np.testing.assert_array_equal(tag[0], s.tag_init[0])
+    np.testing.assert_allclose(np.linalg.norm(cam[:, :4], axis=1), 1.0, atol=1e-12)
+    # expected optimum cost ~ 1/2 * sigma^2 * (residuals - dof)
+    n_res = 8 * s.n_obs
+    expect = 0.5 * s.noise_px ** 2 * (n_res - 6 * (len(cam) + len(tag) - 1))
+    assert abs(out["final_cost"] - expect) < 0.02 * expect
+    sc = oracle.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+    summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, num_threads=8))
+    _assert_same_trace(out, summ, trace)
+    _assert_same_solution(cam, tag, sc, s.tag_wh)

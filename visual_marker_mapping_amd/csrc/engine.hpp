@@ -1,0 +1,157 @@
+// Internal layout of the bundle-adjustment engine (host + device views).  Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vmm_ba.h"
+#include "geom.hpp"
+
+namespace vmm {
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kPart = 32;          // doubles per task partial: 21 (H lower) + 6 (g) + 1 (cost) + pad
+constexpr int kNB = 64;            // dense block size of the reduced system
+constexpr int kKT = 16;            // K tile of the MFMA f64 SYRK
+constexpr int kLdsRow = 80;        // LDS row stride (doubles) for 64-wide tiles: rows k, k+1 land in
+                                   // opposite 32-bank halves for ds_read_b64 (MI355X_MICROARCH LDS)
+
+// One wave's work: up to 64 consecutive observations of one pose in a family-sorted order.
+struct Task {
+    int32_t pose;
+    int32_t begin;
+    int32_t end;
+};
+
+// Observations sorted by one pose family ("own"); SoA so that lane = observation is coalesced.
+struct ObsOrder {
+    int64_t n = 0;          // observations
+    int64_t n_pad = 0;      // SoA stride (multiple of 64)
+    int32_t* own = nullptr;     // [n] pose index in the sorted family
+    int32_t* other = nullptr;   // [n] pose index in the other family
+    int32_t* caller = nullptr;  // [n] position in the caller's observation order
+    double* px = nullptr;       // [8][n_pad]
+    Task* tasks = nullptr;
+    int32_t n_tasks = 0;
+    int32_t* pose_task = nullptr;  // [n_pose+1] task range per pose
+    double* part = nullptr;        // [n_tasks][kPart]
+};
+
+// Device control block of the trust-region loop (Ceres TrustRegionMinimizer +
+// LevenbergMarquardtStrategy state).  Lives in device memory; the host only polls it.
+struct LmCtl {
+    // options (copied at solve start)
+    int32_t max_num_iterations, robustify, jacobi_scaling, max_invalid;
+    double huber_a, function_tolerance, gradient_tolerance, parameter_tolerance;
+    double max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+    // strategy
+    double radius, decrease_factor;
+    int32_t reuse_diagonal, num_invalid;
+    // minimizer
+    double x_cost, cand_cost, model_cost_change, x_norm, initial_cost;
+    int32_t iteration;         // index of the iteration record being built
+    int32_t need_jacobian;     // evaluate residuals+Jacobian at x before the next step
+    int32_t first_eval;        // the pending evaluation is iteration zero
+    int32_t done, termination;
+    int32_t lin_fail;          // a Cholesky pivot was not positive in this iteration
+    int32_t records;           // trace rows pushed (== Ceres summary.iterations.size())
+    int32_t num_successful, num_unsuccessful, num_lm_iterations, num_jac_evals, num_cost_evals;
+    int32_t trace_capacity, pad0;
+    vmm_ba_iteration cur;      // record under construction
+};
+
+struct Engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int rank = 0, world = 1;
+    vmm_ba_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+
+    Intrinsics K;
+    int n_cams = 0, n_tags = 0, fixed_tag = -1;
+    int64_t n_obs = 0;
+    bool elim_cams = true;          // eliminated family E = cameras (else tags)
+    int n_e = 0, n_f = 0;           // pose counts of the eliminated / kept family
+
+    // poses: cameras then tags, 7 doubles each
+    double* cam_qt = nullptr;
+    double* tag_qt = nullptr;
+    double* cam_cand = nullptr;
+    double* tag_cand = nullptr;
+    double* tag_wh = nullptr;
+
+    ObsOrder ordE, ordF;            // observations sorted by the eliminated / kept family
+
+    // normal-equation blocks ("small" buffer, contiguous for one all-reduce):
+    //   H_cam[36*n_cams] | H_tag[36*n_tags] | g_cam[6*n_cams] | g_tag[6*n_tags] | cost | pad
+    double* small = nullptr;
+    size_t small_count = 0;
+    double *H_cam = nullptr, *H_tag = nullptr, *g_cam = nullptr, *g_tag = nullptr, *cost_slot = nullptr;
+    // where the evaluation kernels write (== the pointers above on one GPU, a staging copy that is
+    // all-reduced first when world > 1)
+    double* small_stage = nullptr;
+    double *ev_H_cam = nullptr, *ev_H_tag = nullptr, *ev_g_cam = nullptr, *ev_g_tag = nullptr, *ev_cost = nullptr;
+    double* W = nullptr;            // [36][ordE.n_pad]: J_e^T J_f per observation, E order
+
+    // tangent-space vectors, cameras first then tags (6 each)
+    double *scale = nullptr, *diag = nullptr, *D2 = nullptr, *delta = nullptr;
+    int32_t* active = nullptr;      // per pose (cameras then tags)
+
+    // elimination
+    double* Le = nullptr;           // [n_e][36] Cholesky factors of the damped E blocks
+    double* ze = nullptr;           // [n_e][6]  L_e^{-1} g_e
+    double* Z = nullptr;            // [k_pad][ldz] dense L_e^{-1} W (+ z column), row-major
+    int k_dim = 0, k_pad = 0, split_k = 1, k_chunk = 0;
+    int n_red = 0, n_pad = 0, ldz = 0, n_blk = 0;   // reduced order, padded, leading dim, blocks
+    double* slabs = nullptr;        // [split_k][ldz*ldz]
+    double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
+    double* P = nullptr;            // [kNB][ldz] transposed Cholesky panel
+    double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)
+    double* step_comm = nullptr;    // [6*n_e + 2]: delta of the eliminated family | cross term
+    double* cost_comm = nullptr;    // [2] candidate cost (all-reduced)
+    double* part_cost = nullptr;    // [ordE.n_tasks]
+    double* part_cross = nullptr;   // [ordE.n_tasks]
+
+    LmCtl* ctl = nullptr;           // device
+    LmCtl* ctl_host = nullptr;      // pinned
+    vmm_ba_iteration* trace = nullptr;  // device
+    int trace_capacity = 0;
+
+    std::vector<void*> allocs;
+};
+
+void set_error(const std::string& s);
+
+// ---- kernel launchers (defined in the .hip files) ----
+// kernels_eval.hip
+void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, double huber_a, bool use_ctl);
+void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bool use_ctl);
+void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a);
+void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a,
+                 double* out_scalar);
+void launch_stats(Engine& e, double* part_cam, double* part_tag, double* per_corner_dev);
+void launch_project(hipStream_t st, const Intrinsics& K, int64_t n, const double* pc, double* uv);
+void launch_sum(Engine& e, bool guard, const double* in, int n, double* out);
+// kernels_schur.hip
+void launch_elim(Engine& e);
+void launch_syrk_only(Engine& e);
+void launch_syrk_reduced(Engine& e);
+void launch_add_diag(Engine& e);
+void launch_syrk_raw(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, int row_blk0, int n_row_blk,
+                     int col_blk0, int n_col_blk, int split_k, int k_chunk, double* C, int ldc,
+                     size_t slab_stride, bool subtract);
+void launch_reduce_slabs(hipStream_t st, const LmCtl* ctl, const double* slabs, int split_k, size_t slab_stride,
+                         int ld, int n_rows, int n_cols, double* S);
+// kernels_chol.hip
+void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl);
+// kernels_lm.hip
+void launch_zero_unless_eval(Engine& e, double* buf, size_t n);
+void launch_post_eval(Engine& e, const double* src);
+void launch_lm_begin(Engine& e);
+void launch_backsub(Engine& e);
+void launch_candidate(Engine& e);
+void launch_decide(Engine& e);
+
+} // namespace vmm

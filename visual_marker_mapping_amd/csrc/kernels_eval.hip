@@ -1,0 +1,474 @@
+// Residual / Jacobian evaluation kernels (gfx950).
+//
+// Replaces, for all 4*N_obs corner blocks at once, what Ceres' Evaluator does for the reference:
+// the functor TagReconstructionCostFunction::operator() (include/visual_marker_mapping/
+// TagReconstructionCostFunction.h:101-159) under AutoDiffCostFunction<...,2,3,4,3,4> (:167) with
+// QuaternionParameterization and HuberLoss(1.0) (src/TagReconstructor.cpp:661,721), followed by the
+// J^T J / J^T r formation of the sparse normal-Cholesky solver (src/TagReconstructor.cpp:737-738).
+//
+// Work decomposition: observations are stored twice, sorted by camera and sorted by tag.  One wave
+// = one Task = up to 64 consecutive observations of ONE pose, lane = observation (coalesced SoA
+// loads of the 8 pixel coordinates).  The pass over a family accumulates that family's diagonal
+// 6x6 block and gradient in registers and reduces them with a fixed butterfly, so the sums are
+// deterministic and need no atomics; the pass over the eliminated family additionally writes the
+// 6x6 off-diagonal block W = J_e^T J_f of every observation.
+#include "engine.hpp"
+
+namespace vmm {
+
+struct EvalArgs {
+    Intrinsics K;
+    const Task* tasks;
+    int n_tasks;
+    const int32_t* other;
+    const double* px;
+    int64_t n_pad;
+    const double* own_pose;    // poses of the sorted family
+    const double* other_pose;  // poses of the other family
+    const double* tag_wh;
+    int fixed_tag;
+    int robustify;
+    double huber_a;
+    double* part;              // [n_tasks][kPart]
+    double* W;                 // [36][n_pad] or null
+    const LmCtl* ctl;          // null: always run
+    int guard_need_jacobian;
+};
+
+__device__ __forceinline__ int tri(int a, int b) { return a * (a + 1) / 2 + b; }
+
+template <bool OWN_IS_CAM, bool WRITE_W>
+__global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
+{
+    if (a.ctl) {
+        if (a.ctl->done)
+            return;
+        if (a.guard_need_jacobian && !a.ctl->need_jacobian)
+            return;
+    }
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= a.n_tasks)
+        return;
+    const Task t = a.tasks[wave];
+    const int64_t i = (int64_t)t.begin + lane;
+    const bool valid = i < t.end;
+    const int64_t is = valid ? i : t.begin;
+    const int o = a.other[is];
+
+    Rigid own, oth;
+    load_rigid<true>(a.own_pose + 7 * (int64_t)t.pose, own);
+    load_rigid<true>(a.other_pose + 7 * (int64_t)o, oth);
+    const Rigid& cam = OWN_IS_CAM ? own : oth;
+    const Rigid& tag = OWN_IS_CAM ? oth : own;
+    const int tag_idx = OWN_IS_CAM ? o : t.pose;
+    const double hw = 0.5 * a.tag_wh[2 * tag_idx], hh = 0.5 * a.tag_wh[2 * tag_idx + 1];
+    // a constant (origin) tag contributes no Jacobian columns (src/TagReconstructor.cpp:669-673)
+    const double tag_on = (tag_idx == a.fixed_tag) ? 0.0 : 1.0;
+    const double mask = valid ? 1.0 : 0.0;
+
+    double H[21], g[6], cost = 0.0;
+    double Wacc[WRITE_W ? 36 : 1];
+#pragma unroll
+    for (int k = 0; k < 21; ++k)
+        H[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        g[k] = 0.0;
+    if (WRITE_W) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k)
+            Wacc[k] = 0.0;
+    }
+
+    constexpr bool NEED_JC = OWN_IS_CAM || WRITE_W;
+    constexpr bool NEED_JT = !OWN_IS_CAM || WRITE_W;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // LL, LR, UR, UL (include/visual_marker_mapping/TagReconstructor.h:47-50)
+        const double sx = (c == 1 || c == 2) ? hw : -hw;
+        const double sy = (c >= 2) ? hh : -hh;
+        const double u = a.px[(2 * c) * a.n_pad + is];
+        const double v = a.px[(2 * c + 1) * a.n_pad + is];
+        CornerEval e;
+        eval_corner<NEED_JC, NEED_JT>(a.K, cam, tag, sx, sy, u, v, e);
+        const double s = e.ru * e.ru + e.rv * e.rv;
+        double rho0, wgt;
+        huber(a.robustify != 0, a.huber_a, s, rho0, wgt);
+        wgt *= mask;
+        cost += 0.5 * rho0 * mask;
+        const double w_own = OWN_IS_CAM ? wgt : wgt * tag_on;
+        const double w_oth = OWN_IS_CAM ? wgt * tag_on : wgt;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double res = (r == 0 ? e.ru : e.rv) * wgt;  // corrected residual
+            double jo[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                jo[k] = (OWN_IS_CAM ? e.jc[r][k] : e.jt[r][k]) * w_own;
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                g[p] += jo[p] * res;
+#pragma unroll
+                for (int q = 0; q <= p; ++q)
+                    H[tri(p, q)] += jo[p] * jo[q];
+            }
+            if (WRITE_W) {
+                double jx[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    jx[k] = (OWN_IS_CAM ? e.jt[r][k] : e.jc[r][k]) * w_oth;
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        Wacc[6 * p + q] += jo[p] * jx[q];
+            }
+        }
+    }
+    if (WRITE_W && valid) {
+#pragma unroll
+        for (int k = 0; k < 36; ++k)
+            a.W[(int64_t)k * a.n_pad + i] = Wacc[k];
+    }
+    // wave reduction of the 28 family sums; lane k keeps value k
+    double mine = 0.0;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) {
+        const double s = wave_sum(H[k]);
+        mine = (lane == k) ? s : mine;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double s = wave_sum(g[k]);
+        mine = (lane == 21 + k) ? s : mine;
+    }
+    {
+        const double s = wave_sum(cost);
+        mine = (lane == 27) ? s : mine;
+    }
+    if (lane < 28)
+        a.part[(int64_t)wave * kPart + lane] = mine;
+}
+
+// Sums the task partials of every pose in task order and expands the packed lower triangle.
+__global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, int n_pose,
+                              const int32_t* __restrict__ pose_task, const double* __restrict__ part,
+                              double* __restrict__ Hout, double* __restrict__ gout,
+                              double* __restrict__ pose_cost)
+{
+    if (ctl) {
+        if (ctl->done)
+            return;
+        if (guard_need_jacobian && !ctl->need_jacobian)
+            return;
+    }
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = tid >> 5, k = tid & 31;
+    if (p >= n_pose || k >= 28)
+        return;
+    double s = 0.0;
+    for (int t = pose_task[p]; t < pose_task[p + 1]; ++t)
+        s += part[(int64_t)t * kPart + k];
+    if (k < 21) {
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= k)
+            ++a;
+        const int b = k - a * (a + 1) / 2;
+        Hout[36 * (int64_t)p + 6 * a + b] = s;
+        Hout[36 * (int64_t)p + 6 * b + a] = s;
+    } else if (k < 27) {
+        gout[6 * (int64_t)p + (k - 21)] = s;
+    } else if (pose_cost) {
+        pose_cost[p] = s;
+    }
+}
+
+// out[0] = sum_{i<n} in[i*stride] in a fixed order (one block, pairwise tree over a serial prefix).
+__global__ __launch_bounds__(256) void k_sum(const LmCtl* ctl, int guard_need_jacobian,
+                                             const double* __restrict__ in, int n, int stride,
+                                             double* __restrict__ out)
+{
+    if (ctl) {
+        if (ctl->done)
+            return;
+        if (guard_need_jacobian && !ctl->need_jacobian)
+            return;
+    }
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256)
+        s += in[(int64_t)i * stride];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m)
+            sh[threadIdx.x] += sh[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[0] = sh[0];
+}
+
+// Cost-only pass: 1/2 sum rho(|r|^2) per task (Ceres Evaluator with jacobians == NULL).
+struct CostArgs {
+    Intrinsics K;
+    const Task* tasks;
+    int n_tasks;
+    const int32_t* other;
+    const double* px;
+    int64_t n_pad;
+    const double* own_pose;
+    const double* other_pose;
+    const double* tag_wh;
+    int robustify;
+    double huber_a;
+    double* part;  // [n_tasks]
+    const LmCtl* ctl;
+};
+
+template <bool OWN_IS_CAM>
+__global__ __launch_bounds__(256) void k_cost(const CostArgs a)
+{
+    if (a.ctl && a.ctl->done)
+        return;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= a.n_tasks)
+        return;
+    const Task t = a.tasks[wave];
+    const int64_t i = (int64_t)t.begin + lane;
+    const bool valid = i < t.end;
+    const int64_t is = valid ? i : t.begin;
+    const int o = a.other[is];
+    Rigid own, oth;
+    load_rigid<true>(a.own_pose + 7 * (int64_t)t.pose, own);
+    load_rigid<true>(a.other_pose + 7 * (int64_t)o, oth);
+    const Rigid& cam = OWN_IS_CAM ? own : oth;
+    const Rigid& tag = OWN_IS_CAM ? oth : own;
+    const int tag_idx = OWN_IS_CAM ? o : t.pose;
+    const double hw = 0.5 * a.tag_wh[2 * tag_idx], hh = 0.5 * a.tag_wh[2 * tag_idx + 1];
+    double cost = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double sx = (c == 1 || c == 2) ? hw : -hw;
+        const double sy = (c >= 2) ? hh : -hh;
+        CornerEval e;
+        eval_corner<false, false>(a.K, cam, tag, sx, sy, a.px[(2 * c) * a.n_pad + is],
+                                  a.px[(2 * c + 1) * a.n_pad + is], e);
+        double rho0, wgt;
+        huber(a.robustify != 0, a.huber_a, e.ru * e.ru + e.rv * e.rv, rho0, wgt);
+        cost += 0.5 * rho0;
+    }
+    cost = wave_sum(valid ? cost : 0.0);
+    if (lane == 0)
+        a.part[wave] = cost;
+}
+
+// Reprojection statistics (src/TagReconstructor.cpp:340-455): per task the sum over corners of
+// |projection - observation|_2, and optionally the signed per-corner errors in caller order.
+// Rotation matrices come from the un-normalised quaternion, like Eigen's toRotationMatrix there.
+struct StatsArgs {
+    Intrinsics K;
+    const Task* tasks;
+    int n_tasks;
+    const int32_t* other;
+    const int32_t* caller;
+    const double* px;
+    int64_t n_pad;
+    const double* own_pose;
+    const double* other_pose;
+    const double* tag_wh;
+    double* part;        // [n_tasks]
+    double* per_corner;  // [8*n_obs] caller order, or null
+};
+
+template <bool OWN_IS_CAM>
+__global__ __launch_bounds__(256) void k_stats(const StatsArgs a)
+{
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= a.n_tasks)
+        return;
+    const Task t = a.tasks[wave];
+    const int64_t i = (int64_t)t.begin + lane;
+    const bool valid = i < t.end;
+    const int64_t is = valid ? i : t.begin;
+    const int o = a.other[is];
+    Rigid own, oth;
+    load_rigid<false>(a.own_pose + 7 * (int64_t)t.pose, own);
+    load_rigid<false>(a.other_pose + 7 * (int64_t)o, oth);
+    const Rigid& cam = OWN_IS_CAM ? own : oth;
+    const Rigid& tag = OWN_IS_CAM ? oth : own;
+    const int tag_idx = OWN_IS_CAM ? o : t.pose;
+    const double hw = 0.5 * a.tag_wh[2 * tag_idx], hh = 0.5 * a.tag_wh[2 * tag_idx + 1];
+    double sum = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double sx = (c == 1 || c == 2) ? hw : -hw;
+        const double sy = (c >= 2) ? hh : -hh;
+        CornerEval e;
+        eval_corner<false, false>(a.K, cam, tag, sx, sy, a.px[(2 * c) * a.n_pad + is],
+                                  a.px[(2 * c + 1) * a.n_pad + is], e);
+        sum += sqrt(e.ru * e.ru + e.rv * e.rv);
+        if (a.per_corner && valid) {
+            const int64_t ci = a.caller[i];
+            a.per_corner[8 * ci + 2 * c] = e.ru;
+            a.per_corner[8 * ci + 2 * c + 1] = e.rv;
+        }
+    }
+    sum = wave_sum(valid ? sum : 0.0);
+    if (lane == 0)
+        a.part[wave] = sum;
+}
+
+// CameraModel::projectPoint (src/CameraModel.cpp:6-26) for a batch of camera-frame points.
+__global__ void k_project(Intrinsics K, int64_t n, const double* __restrict__ pc, double* __restrict__ uv)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double X = pc[3 * i], Y = pc[3 * i + 1], Z = pc[3 * i + 2];
+    const double x = X / Z, y = Y / Z;
+    const double r2 = x * x + y * y;
+    const double rad = 1.0 + r2 * (K.k1 + r2 * (K.k2 + r2 * K.k3));
+    const double xd = x * rad + 2.0 * K.p1 * x * y + K.p2 * (r2 + 2.0 * x * x);
+    const double yd = y * rad + 2.0 * K.p2 * x * y + K.p1 * (r2 + 2.0 * y * y);
+    uv[2 * i] = K.fx * xd + K.cx;
+    uv[2 * i + 1] = K.fy * yd + K.cy;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+
+static inline int blocks_for_tasks(int n_tasks) { return (n_tasks + 3) / 4; }
+
+static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, double* W, bool guard)
+{
+    EvalArgs a;
+    a.K = e.K;
+    a.tasks = ord.tasks;
+    a.n_tasks = ord.n_tasks;
+    a.other = ord.other;
+    a.px = ord.px;
+    a.n_pad = ord.n_pad;
+    a.own_pose = own_is_cam ? e.cam_qt : e.tag_qt;
+    a.other_pose = own_is_cam ? e.tag_qt : e.cam_qt;
+    a.tag_wh = e.tag_wh;
+    a.fixed_tag = e.fixed_tag;
+    a.robustify = 0;
+    a.huber_a = 1.0;
+    a.part = ord.part;
+    a.W = W;
+    a.ctl = e.ctl;
+    a.guard_need_jacobian = guard ? 1 : 0;
+    return a;
+}
+
+void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, double huber_a, bool use_ctl)
+{
+    const bool e_is_cam = e.elim_cams;
+    const bool own_is_cam = elim_family ? e_is_cam : !e_is_cam;
+    EvalArgs a = make_eval_args(e, elim_family ? e.ordE : e.ordF, own_is_cam, elim_family ? e.W : nullptr, guard);
+    a.robustify = robustify;
+    a.huber_a = huber_a;
+    if (!use_ctl)
+        a.ctl = nullptr;
+    if (a.n_tasks <= 0)
+        return;
+    const dim3 grid(blocks_for_tasks(a.n_tasks)), block(256);
+    if (elim_family) {
+        if (own_is_cam)
+            hipLaunchKernelGGL((k_eval<true, true>), grid, block, 0, e.stream, a);
+        else
+            hipLaunchKernelGGL((k_eval<false, true>), grid, block, 0, e.stream, a);
+    } else {
+        if (own_is_cam)
+            hipLaunchKernelGGL((k_eval<true, false>), grid, block, 0, e.stream, a);
+        else
+            hipLaunchKernelGGL((k_eval<false, false>), grid, block, 0, e.stream, a);
+    }
+}
+
+// Both family passes, the per-pose sums and the total cost of this rank's observations.
+void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bool use_ctl)
+{
+    const bool e_is_cam = e.elim_cams;
+    launch_eval_pass(e, true, guard, robustify, huber_a, use_ctl);
+    launch_eval_pass(e, false, guard, robustify, huber_a, use_ctl);
+    const LmCtl* ctl = use_ctl ? e.ctl : nullptr;
+    double* H_E = e_is_cam ? e.ev_H_cam : e.ev_H_tag;
+    double* g_E = e_is_cam ? e.ev_g_cam : e.ev_g_tag;
+    double* H_F = e_is_cam ? e.ev_H_tag : e.ev_H_cam;
+    double* g_F = e_is_cam ? e.ev_g_tag : e.ev_g_cam;
+    const int gguard = guard ? 1 : 0;
+    hipLaunchKernelGGL(k_reduce_pose, dim3((e.n_e * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
+                       e.n_e, e.ordE.pose_task, e.ordE.part, H_E, g_E, e.part_cost /* per-pose cost */);
+    hipLaunchKernelGGL(k_reduce_pose, dim3((e.n_f * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
+                       e.n_f, e.ordF.pose_task, e.ordF.part, H_F, g_F, (double*)nullptr);
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1, e.ev_cost);
+}
+
+void launch_sum(Engine& e, bool guard, const double* in, int n, double* out)
+{
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, guard ? e.ctl : (const LmCtl*)nullptr, 0, in, n, 1, out);
+}
+
+void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a)
+{
+    CostArgs a;
+    a.K = e.K;
+    a.tasks = e.ordE.tasks;
+    a.n_tasks = e.ordE.n_tasks;
+    a.other = e.ordE.other;
+    a.px = e.ordE.px;
+    a.n_pad = e.ordE.n_pad;
+    a.own_pose = e.elim_cams ? cam : tag;
+    a.other_pose = e.elim_cams ? tag : cam;
+    a.tag_wh = e.tag_wh;
+    a.robustify = robustify;
+    a.huber_a = huber_a;
+    a.part = e.part_cross;  // scratch distinct from the pose-cost buffer
+    a.ctl = guard ? e.ctl : nullptr;
+    if (a.n_tasks <= 0)
+        return;
+    if (e.elim_cams)
+        hipLaunchKernelGGL((k_cost<true>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);
+    else
+        hipLaunchKernelGGL((k_cost<false>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);
+}
+
+void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a,
+                 double* out_scalar)
+{
+    launch_cost_kernel(e, cam, tag, guard, robustify, huber_a);
+    launch_sum(e, guard, e.part_cross, e.ordE.n_tasks, out_scalar);
+}
+
+void launch_stats(Engine& e, double* part_cam, double* part_tag, double* per_corner_dev)
+{
+    const ObsOrder& oc = e.elim_cams ? e.ordE : e.ordF;  // sorted by camera
+    const ObsOrder& ot = e.elim_cams ? e.ordF : e.ordE;  // sorted by tag
+    StatsArgs a;
+    a.K = e.K;
+    a.tag_wh = e.tag_wh;
+    a.tasks = oc.tasks; a.n_tasks = oc.n_tasks; a.other = oc.other; a.caller = oc.caller; a.px = oc.px;
+    a.n_pad = oc.n_pad; a.own_pose = e.cam_qt; a.other_pose = e.tag_qt; a.part = part_cam;
+    a.per_corner = per_corner_dev;
+    if (a.n_tasks > 0)
+        hipLaunchKernelGGL((k_stats<true>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);
+    a.tasks = ot.tasks; a.n_tasks = ot.n_tasks; a.other = ot.other; a.caller = ot.caller; a.px = ot.px;
+    a.n_pad = ot.n_pad; a.own_pose = e.tag_qt; a.other_pose = e.cam_qt; a.part = part_tag;
+    a.per_corner = nullptr;
+    if (a.n_tasks > 0)
+        hipLaunchKernelGGL((k_stats<false>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);
+}
+
+void launch_project(hipStream_t st, const Intrinsics& K, int64_t n, const double* pc, double* uv)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(k_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, K, n, pc, uv);
+}
+
+} // namespace vmm

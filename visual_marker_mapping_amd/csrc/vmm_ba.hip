@@ -1,0 +1,871 @@
+// libvmm_ba.so -- C-ABI (include/vmm_ba.h) and host driver of the device-resident LM loop.
+//
+// Replaces the body of TagReconstructor::doBundleAdjustment
+// (/root/reference/src/TagReconstructor.cpp:646-743): vmm_ba_create() takes the place of the
+// ceres::Problem construction (:657-724), vmm_ba_solve() of ceres::Solve (:737-738).  No CPU
+// fallback exists: without a HIP device every entry point fails with VMM_BA_ERR_HIP.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+
+namespace vmm {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                         \
+            return VMM_BA_ERR_HIP;                                                                 \
+        }                                                                                          \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(Engine& e, T** p, size_t count, bool zero = true)
+{
+    *p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)p, bytes));
+    e.allocs.push_back(*p);
+    if (zero)
+        HIP_TRY(hipMemsetAsync(*p, 0, bytes, e.stream));
+    return VMM_BA_OK;
+}
+
+template <typename T>
+static int upload(Engine& e, T* dst, const std::vector<T>& src)
+{
+    if (!src.empty())
+        HIP_TRY(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, e.stream));
+    return VMM_BA_OK;
+}
+
+static int round_up(int64_t v, int m) { return (int)(((v + m - 1) / m) * m); }
+
+// Sorts the observations by one pose family (stable counting sort) and cuts each pose's run into
+// wave-sized tasks.
+static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx, const int32_t* other_idx,
+                       const double* px, int64_t n)
+{
+    std::vector<int64_t> start((size_t)n_own + 1, 0);
+    for (int64_t i = 0; i < n; ++i)
+        start[own_idx[i] + 1]++;
+    for (int p = 0; p < n_own; ++p)
+        start[p + 1] += start[p];
+    std::vector<int64_t> pos(start.begin(), start.end() - 1);
+    const int64_t n_pad = std::max<int64_t>(64, round_up(n, 64));
+    std::vector<int32_t> own((size_t)n), other((size_t)n), caller((size_t)n);
+    std::vector<double> pxs((size_t)8 * n_pad, 0.0);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t d = pos[own_idx[i]]++;
+        own[d] = own_idx[i];
+        other[d] = other_idx[i];
+        caller[d] = (int32_t)i;
+        for (int k = 0; k < 8; ++k)
+            pxs[(size_t)k * n_pad + d] = px[8 * i + k];
+    }
+    std::vector<Task> tasks;
+    std::vector<int32_t> pose_task((size_t)n_own + 1, 0);
+    for (int p = 0; p < n_own; ++p) {
+        pose_task[p] = (int32_t)tasks.size();
+        for (int64_t b = start[p]; b < start[p + 1]; b += kWave) {
+            Task t;
+            t.pose = p;
+            t.begin = (int32_t)b;
+            t.end = (int32_t)std::min<int64_t>(b + kWave, start[p + 1]);
+            tasks.push_back(t);
+        }
+    }
+    pose_task[n_own] = (int32_t)tasks.size();
+    o.n = n;
+    o.n_pad = n_pad;
+    o.n_tasks = (int32_t)tasks.size();
+    int rc;
+    if ((rc = dev_alloc(e, &o.own, (size_t)n))) return rc;
+    if ((rc = dev_alloc(e, &o.other, (size_t)n))) return rc;
+    if ((rc = dev_alloc(e, &o.caller, (size_t)n))) return rc;
+    if ((rc = dev_alloc(e, &o.px, (size_t)8 * n_pad))) return rc;
+    if ((rc = dev_alloc(e, &o.tasks, tasks.size()))) return rc;
+    if ((rc = dev_alloc(e, &o.pose_task, pose_task.size()))) return rc;
+    if ((rc = dev_alloc(e, &o.part, tasks.size() * kPart))) return rc;
+    if ((rc = upload(e, o.own, own))) return rc;
+    if ((rc = upload(e, o.other, other))) return rc;
+    if ((rc = upload(e, o.caller, caller))) return rc;
+    if ((rc = upload(e, o.px, pxs))) return rc;
+    if ((rc = upload(e, o.tasks, tasks))) return rc;
+    if ((rc = upload(e, o.pose_task, pose_task))) return rc;
+    HIP_TRY(hipStreamSynchronize(e.stream));  // host vectors go out of scope
+    return VMM_BA_OK;
+}
+
+static int do_allreduce(Engine& e, double* buf, size_t count)
+{
+    if (e.world <= 1)
+        return VMM_BA_OK;
+    if (!e.allreduce) {
+        set_error("world_size > 1 but no all-reduce callback was set (vmm_ba_set_allreduce)");
+        return VMM_BA_ERR_STATE;
+    }
+    if (e.allreduce(e.allreduce_user, buf, count, (void*)e.stream) != 0) {
+        set_error("all-reduce callback failed");
+        return VMM_BA_ERR_COLLECTIVE;
+    }
+    return VMM_BA_OK;
+}
+
+static void destroy_engine(Engine* e)
+{
+    if (!e)
+        return;
+    (void)hipSetDevice(e->device);
+    if (e->stream)
+        (void)hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs)
+        (void)hipFree(p);
+    if (e->ctl_host)
+        (void)hipHostFree(e->ctl_host);
+    if (e->stream)
+        (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+// One LM iteration as a fixed sequence of guarded kernels (+ all-reduces when world > 1).
+static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
+{
+    int rc;
+    launch_eval_passes(e, true, o.robustify, o.huber_a, true);
+    if (e.world > 1) {
+        launch_zero_unless_eval(e, e.small_stage, e.small_count);
+        if ((rc = do_allreduce(e, e.small_stage, e.small_count))) return rc;
+    }
+    launch_post_eval(e, e.world > 1 ? e.small_stage : e.small);
+    launch_lm_begin(e);
+    launch_elim(e);
+    launch_syrk_reduced(e);
+    if ((rc = do_allreduce(e, e.S, (size_t)(e.n_pad + 1) * e.ldz))) return rc;
+    launch_add_diag(e);
+    launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
+    launch_backsub(e);
+    launch_sum(e, true, e.part_cross, e.ordE.n_tasks, e.step_comm + 6 * (size_t)e.n_e);
+    if ((rc = do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1))) return rc;
+    launch_candidate(e);
+    launch_cost(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a, e.cost_comm);
+    if ((rc = do_allreduce(e, e.cost_comm, 1))) return rc;
+    launch_decide(e);
+    HIP_TRY(hipGetLastError());
+    return VMM_BA_OK;
+}
+
+static void init_ctl(LmCtl& c, const vmm_ba_options& o, int trace_capacity)
+{
+    memset(&c, 0, sizeof(c));
+    c.max_num_iterations = o.max_num_iterations;
+    c.robustify = o.robustify;
+    c.jacobi_scaling = o.jacobi_scaling;
+    c.max_invalid = o.max_num_consecutive_invalid_steps;
+    c.huber_a = o.huber_a;
+    c.function_tolerance = o.function_tolerance;
+    c.gradient_tolerance = o.gradient_tolerance;
+    c.parameter_tolerance = o.parameter_tolerance;
+    c.max_radius = o.max_trust_region_radius;
+    c.min_radius = o.min_trust_region_radius;
+    c.min_relative_decrease = o.min_relative_decrease;
+    c.min_lm_diagonal = o.min_lm_diagonal;
+    c.max_lm_diagonal = o.max_lm_diagonal;
+    c.radius = o.initial_trust_region_radius;
+    c.decrease_factor = 2.0;
+    c.need_jacobian = 1;
+    c.first_eval = 1;
+    c.termination = VMM_BA_NO_CONVERGENCE;
+    c.trace_capacity = trace_capacity;
+}
+
+} // namespace vmm
+
+using namespace vmm;
+
+extern "C" {
+
+const char* vmm_ba_last_error(void) { return g_err.c_str(); }
+int vmm_ba_abi_version(void) { return VMM_BA_ABI_VERSION; }
+
+void vmm_ba_default_options(vmm_ba_options* o)
+{
+    // src/TagReconstructor.cpp:725-735 + Ceres Solver::Options defaults
+    memset(o, 0, sizeof(*o));
+    o->max_num_iterations = 400;
+    o->robustify = 1;
+    o->huber_a = 1.0;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->jacobi_scaling = 1;
+    o->num_threads = 1;
+    o->poll_interval = 1;
+}
+
+void vmm_ba_default_create_options(vmm_ba_create_options* o)
+{
+    memset(o, 0, sizeof(*o));
+    o->device = 0;
+    o->elimination = VMM_BA_ELIM_AUTO;
+    o->rank = 0;
+    o->world_size = 1;
+}
+
+int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vmm_ba_handle* out)
+{
+    if (!p || !out) {
+        set_error("null argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    *out = nullptr;
+    vmm_ba_create_options co;
+    if (copt)
+        co = *copt;
+    else
+        vmm_ba_default_create_options(&co);
+    if (p->n_cams <= 0 || p->n_tags <= 0 || p->n_obs < 0 || !p->cam_qt || !p->tag_qt || !p->tag_wh
+        || (p->n_obs > 0 && (!p->obs_cam || !p->obs_tag || !p->obs_px))) {
+        set_error("problem needs >= 1 camera, >= 1 tag and non-null arrays");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    if (p->n_obs >= (int64_t)1 << 31) {
+        set_error("n_obs must fit in 31 bits");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    for (int64_t i = 0; i < p->n_obs; ++i)
+        if (p->obs_cam[i] < 0 || p->obs_cam[i] >= p->n_cams || p->obs_tag[i] < 0 || p->obs_tag[i] >= p->n_tags) {
+            set_error("observation " + std::to_string(i) + " references a camera or tag index out of range");
+            return VMM_BA_ERR_ARGUMENT;
+        }
+    if (p->fixed_tag >= p->n_tags) {
+        set_error("fixed_tag out of range");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    if (co.world_size < 1 || co.rank < 0 || co.rank >= co.world_size) {
+        set_error("bad rank / world_size");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: libvmm_ba has no CPU fallback");
+        return VMM_BA_ERR_HIP;
+    }
+    if (co.device < 0 || co.device >= ndev) {
+        set_error("device ordinal out of range");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine* ep = new Engine();
+    Engine& e = *ep;
+    int rc = VMM_BA_OK;
+    auto fail = [&](int code) {
+        destroy_engine(ep);
+        return code;
+    };
+    e.device = co.device;
+    if (hipSetDevice(e.device) != hipSuccess || hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipSetDevice / hipStreamCreate failed");
+        e.stream = nullptr;
+        return fail(VMM_BA_ERR_HIP);
+    }
+    e.rank = co.rank;
+    e.world = co.world_size;
+    e.K.fx = p->intr[0]; e.K.fy = p->intr[1]; e.K.cx = p->intr[2]; e.K.cy = p->intr[3];
+    e.K.k1 = p->dist[0]; e.K.k2 = p->dist[1]; e.K.p1 = p->dist[2]; e.K.p2 = p->dist[3]; e.K.k3 = p->dist[4];
+    e.n_cams = p->n_cams;
+    e.n_tags = p->n_tags;
+    e.fixed_tag = p->fixed_tag;
+    e.n_obs = p->n_obs;
+    int elim = co.elimination;
+    if (elim == VMM_BA_ELIM_AUTO)
+        elim = (p->n_cams >= p->n_tags) ? VMM_BA_ELIM_CAMERAS : VMM_BA_ELIM_TAGS;
+    if (elim != VMM_BA_ELIM_CAMERAS && elim != VMM_BA_ELIM_TAGS) {
+        set_error("bad elimination mode");
+        return fail(VMM_BA_ERR_ARGUMENT);
+    }
+    e.elim_cams = (elim == VMM_BA_ELIM_CAMERAS);
+    e.n_e = e.elim_cams ? e.n_cams : e.n_tags;
+    e.n_f = e.elim_cams ? e.n_tags : e.n_cams;
+    const int n_pose = e.n_cams + e.n_tags;
+
+    // poses
+    if ((rc = dev_alloc(e, &e.cam_qt, (size_t)7 * e.n_cams))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.tag_qt, (size_t)7 * e.n_tags))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.cam_cand, (size_t)7 * e.n_cams))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.tag_cand, (size_t)7 * e.n_tags))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.tag_wh, (size_t)2 * e.n_tags))) return fail(rc);
+    if (hipMemcpyAsync(e.cam_qt, p->cam_qt, sizeof(double) * 7 * e.n_cams, hipMemcpyHostToDevice, e.stream) != hipSuccess
+        || hipMemcpyAsync(e.tag_qt, p->tag_qt, sizeof(double) * 7 * e.n_tags, hipMemcpyHostToDevice, e.stream) != hipSuccess
+        || hipMemcpyAsync(e.tag_wh, p->tag_wh, sizeof(double) * 2 * e.n_tags, hipMemcpyHostToDevice, e.stream) != hipSuccess
+        || hipStreamSynchronize(e.stream) != hipSuccess) {
+        set_error("pose upload failed");
+        return fail(VMM_BA_ERR_HIP);
+    }
+
+    // observation orders
+    const int32_t* own_e = e.elim_cams ? p->obs_cam : p->obs_tag;
+    const int32_t* own_f = e.elim_cams ? p->obs_tag : p->obs_cam;
+    if ((rc = build_order(e, e.ordE, e.n_e, own_e, own_f, p->obs_px, p->n_obs))) return fail(rc);
+    if ((rc = build_order(e, e.ordF, e.n_f, own_f, own_e, p->obs_px, p->n_obs))) return fail(rc);
+
+    // normal-equation blocks
+    e.small_count = (size_t)42 * n_pose + 2;
+    if ((rc = dev_alloc(e, &e.small, e.small_count))) return fail(rc);
+    e.H_cam = e.small;
+    e.H_tag = e.H_cam + (size_t)36 * e.n_cams;
+    e.g_cam = e.H_tag + (size_t)36 * e.n_tags;
+    e.g_tag = e.g_cam + (size_t)6 * e.n_cams;
+    e.cost_slot = e.g_tag + (size_t)6 * e.n_tags;
+    if (e.world > 1) {
+        if ((rc = dev_alloc(e, &e.small_stage, e.small_count))) return fail(rc);
+    } else {
+        e.small_stage = e.small;
+    }
+    e.ev_H_cam = e.small_stage;
+    e.ev_H_tag = e.ev_H_cam + (size_t)36 * e.n_cams;
+    e.ev_g_cam = e.ev_H_tag + (size_t)36 * e.n_tags;
+    e.ev_g_tag = e.ev_g_cam + (size_t)6 * e.n_cams;
+    e.ev_cost = e.ev_g_tag + (size_t)6 * e.n_tags;
+    if ((rc = dev_alloc(e, &e.W, (size_t)36 * e.ordE.n_pad))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.scale, (size_t)6 * n_pose))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.diag, (size_t)6 * n_pose))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.D2, (size_t)6 * n_pose))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.delta, (size_t)6 * n_pose))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.active, (size_t)n_pose))) return fail(rc);
+
+    // elimination / reduced system geometry
+    e.n_red = 6 * e.n_f;
+    e.n_pad = round_up(e.n_red, kNB);
+    e.n_blk = e.n_pad / kNB;
+    e.ldz = e.n_pad + kNB;
+    e.k_dim = 6 * e.n_e;
+    {
+        const int tiles = e.n_blk * (e.n_blk + 1) / 2 + e.n_blk;
+        int split = (1024 + tiles - 1) / tiles;
+        split = std::max(1, std::min(split, 16));
+        const int max_split = std::max(1, e.k_dim / 64);
+        split = std::min(split, max_split);
+        e.split_k = split;
+        e.k_chunk = round_up((e.k_dim + split - 1) / split, kKT);
+        e.k_pad = e.k_chunk * split;
+    }
+    if ((rc = dev_alloc(e, &e.Le, (size_t)36 * e.n_e))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.ze, (size_t)6 * e.n_e))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.Z, (size_t)e.k_pad * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.slabs, (size_t)e.split_k * e.ldz * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.P, (size_t)kNB * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.step_comm, (size_t)6 * e.n_e + 2))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.cost_comm, 2))) return fail(rc);
+    const size_t n_part = (size_t)std::max<int>(e.ordE.n_tasks, e.n_e) + 1;
+    if ((rc = dev_alloc(e, &e.part_cost, n_part))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.part_cross, n_part))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.ctl, 1))) return fail(rc);
+    if (hipHostMalloc((void**)&e.ctl_host, sizeof(LmCtl)) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        e.ctl_host = nullptr;
+        return fail(VMM_BA_ERR_HIP);
+    }
+    memset(e.ctl_host, 0, sizeof(LmCtl));
+    e.trace_capacity = 0;
+    if (hipStreamSynchronize(e.stream) != hipSuccess) {
+        set_error("create: device synchronisation failed");
+        return fail(VMM_BA_ERR_HIP);
+    }
+    *out = reinterpret_cast<vmm_ba_handle>(ep);
+    return VMM_BA_OK;
+}
+
+void vmm_ba_destroy(vmm_ba_handle h) { destroy_engine(reinterpret_cast<Engine*>(h)); }
+
+int vmm_ba_set_allreduce(vmm_ba_handle h, vmm_ba_allreduce_fn fn, void* user)
+{
+    if (!h) {
+        set_error("null handle");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    e.allreduce = fn;
+    e.allreduce_user = user;
+    return VMM_BA_OK;
+}
+
+int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt)
+{
+    if (!h) {
+        set_error("null handle");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    HIP_TRY(hipSetDevice(e.device));
+    if (cam_qt)
+        HIP_TRY(hipMemcpyAsync(e.cam_qt, cam_qt, sizeof(double) * 7 * e.n_cams, hipMemcpyHostToDevice, e.stream));
+    if (tag_qt)
+        HIP_TRY(hipMemcpyAsync(e.tag_qt, tag_qt, sizeof(double) * 7 * e.n_tags, hipMemcpyHostToDevice, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    return VMM_BA_OK;
+}
+
+int vmm_ba_get_state(vmm_ba_handle h, double* cam_qt, double* tag_qt)
+{
+    if (!h) {
+        set_error("null handle");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    HIP_TRY(hipSetDevice(e.device));
+    if (cam_qt)
+        HIP_TRY(hipMemcpyAsync(cam_qt, e.cam_qt, sizeof(double) * 7 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
+    if (tag_qt)
+        HIP_TRY(hipMemcpyAsync(tag_qt, e.tag_qt, sizeof(double) * 7 * e.n_tags, hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    return VMM_BA_OK;
+}
+
+int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
+{
+    if (!h || !s) {
+        set_error("null argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    vmm_ba_options o;
+    if (opt)
+        o = *opt;
+    else
+        vmm_ba_default_options(&o);
+    if (o.max_num_iterations < 0 || o.poll_interval < 0 || !(o.initial_trust_region_radius > 0.0)) {
+        set_error("bad solver options");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    HIP_TRY(hipSetDevice(e.device));
+    const auto t0 = std::chrono::steady_clock::now();
+    vmm_ba_iteration* user_trace = s->trace;
+    const int user_cap = s->trace ? s->trace_capacity : 0;
+    memset(s, 0, sizeof(*s));
+    s->trace = user_trace;
+    s->trace_capacity = user_cap;
+
+    // device trace buffer sized for this call
+    const int need_cap = std::max(user_cap, 1);
+    if (need_cap > e.trace_capacity) {
+        int rc;
+        if ((rc = dev_alloc(e, &e.trace, (size_t)need_cap, false))) return rc;
+        e.trace_capacity = need_cap;
+    }
+    init_ctl(*e.ctl_host, o, user_cap);
+    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+
+    const int poll = std::max(1, o.poll_interval);
+    const int64_t max_steps = (int64_t)o.max_num_iterations + 2;
+    int64_t enq = 0;
+    for (;;) {
+        int rc;
+        for (int k = 0; k < poll && enq < max_steps; ++k, ++enq)
+            if ((rc = enqueue_iteration(e, o))) return rc;
+        HIP_TRY(hipMemcpyAsync(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream));
+        HIP_TRY(hipStreamSynchronize(e.stream));
+        if (e.ctl_host->done)
+            break;
+        if (enq >= max_steps) {
+            set_error("LM loop did not terminate within max_num_iterations + 2 passes");
+            return VMM_BA_ERR_STATE;
+        }
+    }
+    const LmCtl& c = *e.ctl_host;
+    s->termination_type = c.termination;
+    s->iterations = c.records;
+    s->num_successful_steps = c.num_successful;
+    s->num_unsuccessful_steps = c.num_unsuccessful;
+    s->num_lm_iterations = c.num_lm_iterations;
+    s->num_jacobian_evals = c.num_jac_evals;
+    s->num_cost_evals = c.num_cost_evals;
+    s->elimination = e.elim_cams ? VMM_BA_ELIM_CAMERAS : VMM_BA_ELIM_TAGS;
+    s->initial_cost = c.initial_cost;
+    s->final_cost = c.x_cost;
+    if (user_trace && user_cap > 0) {
+        const int n = std::min(c.records, user_cap);
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync(user_trace, e.trace, sizeof(vmm_ba_iteration) * n, hipMemcpyDeviceToHost, e.stream));
+            HIP_TRY(hipStreamSynchronize(e.stream));
+        }
+    }
+    s->time_solve_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return VMM_BA_OK;
+}
+
+int vmm_ba_cost(vmm_ba_handle h, int robustify, double huber_a, double* cost)
+{
+    if (!h || !cost) {
+        set_error("null argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    HIP_TRY(hipSetDevice(e.device));
+    launch_cost(e, e.cam_qt, e.tag_qt, false, robustify, huber_a, e.cost_comm);
+    int rc;
+    if ((rc = do_allreduce(e, e.cost_comm, 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(cost, e.cost_comm, sizeof(double), hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    return VMM_BA_OK;
+}
+
+int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per_tag_mean, double* avg,
+                              double* per_corner)
+{
+    if (!h) {
+        set_error("null handle");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    HIP_TRY(hipSetDevice(e.device));
+    const ObsOrder& oc = e.elim_cams ? e.ordE : e.ordF;
+    const ObsOrder& ot = e.elim_cams ? e.ordF : e.ordE;
+    double *d_pc = nullptr, *d_pt = nullptr, *d_corner = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_pc, sizeof(double) * std::max(1, oc.n_tasks)));
+    HIP_TRY(hipMalloc((void**)&d_pt, sizeof(double) * std::max(1, ot.n_tasks)));
+    if (per_corner && e.n_obs > 0)
+        HIP_TRY(hipMalloc((void**)&d_corner, sizeof(double) * 8 * e.n_obs));
+    launch_stats(e, d_pc, d_pt, d_corner);
+    std::vector<double> pc((size_t)oc.n_tasks), pt((size_t)ot.n_tasks);
+    std::vector<Task> tc((size_t)oc.n_tasks), tt((size_t)ot.n_tasks);
+    hipError_t err = hipSuccess;
+    if (oc.n_tasks > 0) {
+        err = hipMemcpyAsync(pc.data(), d_pc, sizeof(double) * pc.size(), hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess) err = hipMemcpyAsync(pt.data(), d_pt, sizeof(double) * pt.size(), hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess) err = hipMemcpyAsync(tc.data(), oc.tasks, sizeof(Task) * tc.size(), hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess) err = hipMemcpyAsync(tt.data(), ot.tasks, sizeof(Task) * tt.size(), hipMemcpyDeviceToHost, e.stream);
+    }
+    if (err == hipSuccess && d_corner)
+        err = hipMemcpyAsync(per_corner, d_corner, sizeof(double) * 8 * e.n_obs, hipMemcpyDeviceToHost, e.stream);
+    if (err == hipSuccess)
+        err = hipStreamSynchronize(e.stream);
+    (void)hipFree(d_pc);
+    (void)hipFree(d_pt);
+    if (d_corner)
+        (void)hipFree(d_corner);
+    if (err != hipSuccess) {
+        set_error(std::string("reprojection_stats: ") + hipGetErrorString(err));
+        return VMM_BA_ERR_HIP;
+    }
+    // per-pose means in task order (the reference accumulates in observation order,
+    // src/TagReconstructor.cpp:344-368; the value differs only in summation order)
+    std::vector<double> sc((size_t)e.n_cams, 0.0), st((size_t)e.n_tags, 0.0);
+    std::vector<int64_t> nc((size_t)e.n_cams, 0), nt((size_t)e.n_tags, 0);
+    for (size_t k = 0; k < tc.size(); ++k) {
+        sc[tc[k].pose] += pc[k];
+        nc[tc[k].pose] += 4 * (int64_t)(tc[k].end - tc[k].begin);
+    }
+    for (size_t k = 0; k < tt.size(); ++k) {
+        st[tt[k].pose] += pt[k];
+        nt[tt[k].pose] += 4 * (int64_t)(tt[k].end - tt[k].begin);
+    }
+    if (per_cam_mean)
+        for (int c = 0; c < e.n_cams; ++c)
+            per_cam_mean[c] = nc[c] ? sc[c] / (double)nc[c] : -1.0;   // :379-383
+    double a = 0.0;
+    int64_t tot = 0;
+    for (int t = 0; t < e.n_tags; ++t) {
+        if (nt[t]) {
+            a += st[t];
+            tot += nt[t];
+        }
+        if (per_tag_mean)
+            per_tag_mean[t] = nt[t] ? st[t] / (double)nt[t] : NAN;
+    }
+    if (avg)
+        *avg = tot ? a / (double)tot : 0.0;                            // :416-426
+    return VMM_BA_OK;
+}
+
+int vmm_ba_project_points(const double intr[4], const double dist[5], int64_t n, const double* points_cam,
+                          double* uv, int device)
+{
+    if (!intr || !dist || n < 0 || (n > 0 && (!points_cam || !uv))) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    if (n == 0)
+        return VMM_BA_OK;
+    HIP_TRY(hipSetDevice(device));
+    Intrinsics K;
+    K.fx = intr[0]; K.fy = intr[1]; K.cx = intr[2]; K.cy = intr[3];
+    K.k1 = dist[0]; K.k2 = dist[1]; K.p1 = dist[2]; K.p2 = dist[3]; K.k3 = dist[4];
+    double *d_p = nullptr, *d_uv = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_p, sizeof(double) * 3 * n));
+    if (hipMalloc((void**)&d_uv, sizeof(double) * 2 * n) != hipSuccess) {
+        (void)hipFree(d_p);
+        set_error("hipMalloc failed");
+        return VMM_BA_ERR_HIP;
+    }
+    hipError_t err = hipMemcpy(d_p, points_cam, sizeof(double) * 3 * n, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        launch_project(nullptr, K, n, d_p, d_uv);
+        err = hipMemcpy(uv, d_uv, sizeof(double) * 2 * n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_p);
+    (void)hipFree(d_uv);
+    if (err != hipSuccess) {
+        set_error(std::string("project_points: ") + hipGetErrorString(err));
+        return VMM_BA_ERR_HIP;
+    }
+    return VMM_BA_OK;
+}
+
+int vmm_ba_eval_blocks(vmm_ba_handle h, int robustify, double huber_a, double* cost, double* V, double* U,
+                       double* W, double* g_cam, double* g_tag)
+{
+    if (!h) {
+        set_error("null handle");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    HIP_TRY(hipSetDevice(e.device));
+    launch_eval_passes(e, false, robustify, huber_a, false);
+    HIP_TRY(hipGetLastError());
+    if (cost) HIP_TRY(hipMemcpyAsync(cost, e.ev_cost, sizeof(double), hipMemcpyDeviceToHost, e.stream));
+    if (V) HIP_TRY(hipMemcpyAsync(V, e.ev_H_cam, sizeof(double) * 36 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
+    if (U) HIP_TRY(hipMemcpyAsync(U, e.ev_H_tag, sizeof(double) * 36 * e.n_tags, hipMemcpyDeviceToHost, e.stream));
+    if (g_cam) HIP_TRY(hipMemcpyAsync(g_cam, e.ev_g_cam, sizeof(double) * 6 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
+    if (g_tag) HIP_TRY(hipMemcpyAsync(g_tag, e.ev_g_tag, sizeof(double) * 6 * e.n_tags, hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    if (W && e.n_obs > 0) {
+        std::vector<double> w((size_t)36 * e.ordE.n_pad);
+        std::vector<int32_t> caller((size_t)e.n_obs);
+        HIP_TRY(hipMemcpy(w.data(), e.W, sizeof(double) * w.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(caller.data(), e.ordE.caller, sizeof(int32_t) * caller.size(), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < e.n_obs; ++i)
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) {
+                    // device: rows = eliminated family's tangent, columns = kept family's
+                    const double v = w[(size_t)(6 * a + b) * e.ordE.n_pad + i];
+                    const int ca = e.elim_cams ? a : b, tb = e.elim_cams ? b : a;
+                    W[(size_t)36 * caller[i] + 6 * ca + tb] = v;
+                }
+    }
+    return VMM_BA_OK;
+}
+
+// Minimal engine for the dense test entry points: stream + panel buffer + a control block.
+static int make_scratch(Engine& e, int device, int ld)
+{
+    e.device = device;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+    int rc;
+    if ((rc = dev_alloc(e, &e.P, (size_t)kNB * ld))) return rc;
+    if ((rc = dev_alloc(e, &e.ctl, 1))) return rc;
+    return VMM_BA_OK;
+}
+
+static void free_scratch(Engine& e)
+{
+    if (e.stream)
+        (void)hipStreamSynchronize(e.stream);
+    for (void* p : e.allocs)
+        (void)hipFree(p);
+    if (e.stream)
+        (void)hipStreamDestroy(e.stream);
+    e.allocs.clear();
+    e.stream = nullptr;
+}
+
+int vmm_ba_dense_spd_solve(int device, int n, const double* A, const double* b, double* x, int* info)
+{
+    if (n <= 0 || !A || !b || !x) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    const int n_pad = round_up(n, kNB), ld = n_pad + kNB;
+    Engine e;
+    int rc = make_scratch(e, device, ld);
+    double *S = nullptr, *y = nullptr;
+    if (!rc) rc = dev_alloc(e, &S, (size_t)ld * ld);
+    if (!rc) rc = dev_alloc(e, &y, (size_t)ld);
+    if (rc) {
+        free_scratch(e);
+        return rc;
+    }
+    std::vector<double> hs((size_t)ld * ld, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j)
+            hs[(size_t)i * ld + j] = A[(size_t)i * n + j];
+    for (int i = n; i < n_pad; ++i)
+        hs[(size_t)i * ld + i] = 1.0;
+    for (int j = 0; j < n; ++j)
+        hs[(size_t)n_pad * ld + j] = b[j];
+    hipError_t err = hipMemcpyAsync(S, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, e.stream);
+    if (err == hipSuccess) {
+        launch_cholesky_solve(e, S, n_pad, ld, y, e.ctl);
+        err = hipGetLastError();
+    }
+    LmCtl c;
+    memset(&c, 0, sizeof(c));
+    if (err == hipSuccess) err = hipMemcpyAsync(x, y, sizeof(double) * n, hipMemcpyDeviceToHost, e.stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(&c, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
+    free_scratch(e);
+    if (err != hipSuccess) {
+        set_error(std::string("dense_spd_solve: ") + hipGetErrorString(err));
+        return VMM_BA_ERR_HIP;
+    }
+    if (info)
+        *info = c.lin_fail;
+    return VMM_BA_OK;
+}
+
+int vmm_ba_dense_syrk(int device, int k, int n, const double* Zh, double* C)
+{
+    if (k <= 0 || n <= 0 || !Zh || !C) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    const int n_pad = round_up(n, kNB), ld = n_pad;
+    const int n_blk = n_pad / kNB;
+    const int split = (k >= 64) ? 2 : 1;
+    const int k_chunk = round_up((k + split - 1) / split, kKT);
+    const int k_pad = k_chunk * split;
+    Engine e;
+    int rc = make_scratch(e, device, ld);
+    double *Z = nullptr, *slabs = nullptr, *S = nullptr;
+    if (!rc) rc = dev_alloc(e, &Z, (size_t)k_pad * ld);
+    if (!rc) rc = dev_alloc(e, &slabs, (size_t)split * ld * ld);
+    if (!rc) rc = dev_alloc(e, &S, (size_t)ld * ld);
+    if (rc) {
+        free_scratch(e);
+        return rc;
+    }
+    std::vector<double> hz((size_t)k_pad * ld, 0.0);
+    for (int r = 0; r < k; ++r)
+        for (int c = 0; c < n; ++c)
+            hz[(size_t)r * ld + c] = Zh[(size_t)r * n + c];
+    hipError_t err = hipMemcpyAsync(Z, hz.data(), sizeof(double) * hz.size(), hipMemcpyHostToDevice, e.stream);
+    std::vector<double> hs((size_t)ld * ld, 0.0);
+    if (err == hipSuccess) {
+        launch_syrk_raw(e.stream, nullptr, Z, ld, 0, n_blk, 0, n_blk, split, k_chunk, slabs, ld, (size_t)ld * ld, false);
+        launch_reduce_slabs(e.stream, nullptr, slabs, split, (size_t)ld * ld, ld, n_pad, n_pad, S);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(hs.data(), S, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, e.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
+    free_scratch(e);
+    if (err != hipSuccess) {
+        set_error(std::string("dense_syrk: ") + hipGetErrorString(err));
+        return VMM_BA_ERR_HIP;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+            C[(size_t)i * n + j] = (j <= i) ? -hs[(size_t)i * ld + j] : -hs[(size_t)j * ld + i];
+    return VMM_BA_OK;
+}
+
+int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vmm_ba_kernel_times* out)
+{
+    if (!h || !out || reps <= 0) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (e.world > 1) {
+        set_error("time_kernels is a single-GPU diagnostic");
+        return VMM_BA_ERR_STATE;
+    }
+    vmm_ba_options o;
+    if (opt)
+        o = *opt;
+    else
+        vmm_ba_default_options(&o);
+    HIP_TRY(hipSetDevice(e.device));
+    memset(out, 0, sizeof(*out));
+    out->n_obs = e.n_obs;
+    out->reduced_dim = e.n_red;
+    out->elim_dim = e.k_dim;
+    // keep the caller's state: timing runs real iterations
+    std::vector<double> cam0((size_t)7 * e.n_cams), tag0((size_t)7 * e.n_tags);
+    int rc;
+    if ((rc = vmm_ba_get_state(h, cam0.data(), tag0.data()))) return rc;
+    if (e.trace_capacity < 1) {
+        if ((rc = dev_alloc(e, &e.trace, 1, false))) return rc;
+        e.trace_capacity = 1;
+    }
+    vmm_ba_options ot = o;
+    ot.max_num_iterations = 1 << 30;
+    ot.function_tolerance = 0.0;
+    ot.parameter_tolerance = 0.0;
+    ot.gradient_tolerance = 0.0;
+    init_ctl(*e.ctl_host, ot, 0);
+    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+    if ((rc = enqueue_iteration(e, ot))) return rc;   // populates every buffer of an iteration
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    auto timed = [&](auto&& fn, auto&& prep, double* ms_out) -> int {
+        double total = 0.0;
+        for (int r = 0; r < reps; ++r) {
+            prep();
+            HIP_TRY(hipEventRecord(ev0, e.stream));
+            fn();
+            HIP_TRY(hipEventRecord(ev1, e.stream));
+            HIP_TRY(hipEventSynchronize(ev1));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+            total += ms;
+        }
+        *ms_out = total / reps;
+        return VMM_BA_OK;
+    };
+    auto nop = [] {};
+    // the guards read ctl->done / lin_fail only; both are 0 after the priming iteration unless it failed
+    HIP_TRY(hipMemcpy(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost));
+    e.ctl_host->done = 0;
+    e.ctl_host->lin_fail = 0;
+    HIP_TRY(hipMemcpy(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice));
+    if ((rc = timed([&] { launch_eval_pass(e, true, false, o.robustify, o.huber_a, false); }, nop, &out->eval_elim_ms))) return rc;
+    if ((rc = timed([&] { launch_eval_pass(e, false, false, o.robustify, o.huber_a, false); }, nop, &out->eval_keep_ms))) return rc;
+    if ((rc = timed([&] { launch_cost_kernel(e, e.cam_qt, e.tag_qt, false, o.robustify, o.huber_a); }, nop, &out->cost_ms))) return rc;
+    if ((rc = timed([&] { launch_elim(e); }, nop, &out->form_z_ms))) return rc;
+    if ((rc = timed([&] { launch_syrk_only(e); }, nop, &out->syrk_ms))) return rc;
+    if ((rc = timed([&] { launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl); },
+                    [&] {
+                        launch_syrk_reduced(e);
+                        launch_add_diag(e);
+                    },
+                    &out->cholesky_ms)))
+        return rc;
+    if ((rc = timed([&] { launch_backsub(e); }, nop, &out->backsub_ms))) return rc;
+    // whole iterations from the caller's state
+    if ((rc = vmm_ba_set_state(h, cam0.data(), tag0.data()))) return rc;
+    init_ctl(*e.ctl_host, ot, 0);
+    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+    HIP_TRY(hipEventRecord(ev0, e.stream));
+    for (int r = 0; r < reps; ++r)
+        if ((rc = enqueue_iteration(e, ot))) return rc;
+    HIP_TRY(hipEventRecord(ev1, e.stream));
+    HIP_TRY(hipEventSynchronize(ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    out->lm_iteration_ms = ms / reps;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return vmm_ba_set_state(h, cam0.data(), tag0.data());
+}
+
+} // extern "C"
