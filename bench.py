@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- LM iterations/s and residual-evaluations/s of the bundle-adjustment hot path.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): synthetic scene of
+500 images x 200 tags, every image sees every tag (100 000 tag observations = 400 000 corner
+residual blocks), f64 residuals/Jacobians, non-robust unless --config 5.  One "step" = one
+Levenberg-Marquardt iteration (linear solve + candidate cost evaluation, + a Jacobian evaluation
+after every accepted step) following Ceres' trust-region policy.  Steps are executed as back-to-back
+solves from the perturbed initial state (each solve runs its natural ~7 iterations); the last solve
+is capped so that exactly --steps iterations are timed.  Inputs are resident in HBM before the timed
+region; only 700 poses (39 KB) are re-uploaded per solve.
+
+N > 1: launched by torch.distributed.run, one rank per GPU, observations sharded by camera, the
+reduced system all-reduced over RCCL -> "scaling": "strong" (the scene is fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = FP64 vector datasheet rate;
+                              # MI355X_MICROARCH.md has no f64 row, tools/mfma_f64_peak.hip measures it
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=140)
+    ap.add_argument("--warmup", type=int, default=14)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs index (1-based)")
+    ap.add_argument("--visibility", type=float, default=1.0)
+    ap.add_argument("--poll", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--elimination", choices=["auto", "cams", "tags"], default="auto")
+    return ap.parse_args()
+
+
+def run_steps(ba, eng, s, opts_kw, n_steps):
+    """Runs exactly n_steps LM iterations as consecutive solves from the initial state."""
+    done = 0
+    evals = 0
+    solves = 0
+    last = None
+    while done < n_steps:
+        ba.set_state(s.cam_init, s.tag_init)
+        out = ba.solve(eng.default_options(max_num_iterations=n_steps - done, **opts_kw))
+        if out["num_lm_iterations"] <= 0:
+            raise RuntimeError("solve made no progress: %r" % (out,))
+        done += out["num_lm_iterations"]
+        evals += out["num_cost_evals"] + out["num_jacobian_evals"]
+        solves += 1
+        last = out
+    return done, evals, solves, last
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd import distributed as vdist
+    from visual_marker_mapping_amd.synthetic import make_scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    overrides = {}
+    if a.visibility < 1.0:
+        overrides["visibility"] = a.visibility
+    s = make_scene(a.config, **overrides)
+    n_cams, n_tags = len(s.cam_init), len(s.tag_init)
+    elim = {"auto": eng.ELIM_AUTO, "cams": eng.ELIM_CAMERAS, "tags": eng.ELIM_TAGS}[a.elimination]
+    elim_cams = None if a.elimination == "auto" else (a.elimination == "cams")
+    idx, elim_cams = vdist.shard_observations(s.obs_cam, s.obs_tag, n_cams, n_tags, rank, world, elim_cams)
+    t0 = time.time()
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam[idx],
+                            s.obs_tag[idx], s.obs_px[idx], device=local_rank, elimination=elim, rank=rank,
+                            world_size=world)
+    setup_s = time.time() - t0
+    if world > 1:
+        ba.set_allreduce(vdist.make_allreduce(local_rank))
+    robust = 1 if s.robustify else 0
+    opts_kw = dict(robustify=robust, poll_interval=a.poll)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.warmup > 0:
+        run_steps(ba, eng, s, opts_kw, a.warmup)
+    fence()
+    t0 = time.perf_counter()
+    done, evals, solves, last = run_steps(ba, eng, s, opts_kw, a.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert done == a.steps, (done, a.steps)
+
+    line = None
+    if rank == 0:
+        n_obs_total = s.n_obs
+        it_per_s = a.steps / elapsed
+        res_evals_per_s = 4.0 * n_obs_total * evals / elapsed
+        line = {
+            "metric": "lm_iterations_per_sec", "value": it_per_s, "unit": "LM iterations/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[%d]: %d images x %d tags, visibility %.2f, %d tag observations "
+                                   "(%d corner residual blocks), %s, perturbed initial guess"
+                                   % (a.config - 1, n_cams, n_tags, a.visibility, n_obs_total, 4 * n_obs_total,
+                                      "Huber(1.0)" if robust else "no loss"),
+                       "eliminated_family": "cameras" if elim_cams else "tags",
+                       "reduced_system_order": 6 * (n_tags if elim_cams else n_cams),
+                       "solves_timed": solves, "lm_iterations_per_solve": last["num_lm_iterations"],
+                       "sharding": "observations by %s" % ("camera" if elim_cams else "tag")},
+            "residual_evals_per_sec": res_evals_per_s,
+            "setup_s": setup_s,
+        }
+    if world == 1:
+        ba.set_state(s.cam_init, s.tag_init)
+        kt = ba.time_kernels(eng.default_options(**opts_kw), reps=10)
+        n_obs = kt["n_obs"]
+        n_red, k_dim = kt["reduced_dim"], kt["elim_dim"]
+        n_aug = n_red + 1
+        kern = {
+            # algorithmic bytes per tag observation: SURVEY.md 8(d) -- 360 B for the fused
+            # residual+Jacobian+accumulate evaluation (72 B in + one f64 6x6 W block out), 72 B cost-only
+            "eval_jacobian": {"ms": kt["eval_elim_ms"] + kt["eval_keep_ms"], "bound": "hbm",
+                              "alg": 360.0 * n_obs, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            "eval_cost": {"ms": kt["cost_ms"], "bound": "hbm", "alg": 72.0 * n_obs, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s"},
+            # S = Z^T Z, lower triangle incl. the rhs row: (n+1)(n+2)/2 * K multiply-adds
+            "schur_syrk": {"ms": kt["syrk_ms"], "bound": "mfma", "alg": 1.0 * n_aug * (n_aug + 1) * k_dim,
+                           "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"},
+            # Cholesky n^3/3 + forward/backward substitution 2 n^2
+            "cholesky_solve": {"ms": kt["cholesky_ms"], "bound": "mfma",
+                               "alg": n_red ** 3 / 3.0 + 2.0 * n_red ** 2, "peak": F64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s"},
+        }
+        for k, v in kern.items():
+            scale = 1e-9 if v["unit"] == "GB/s" else 1e-12
+            v["achieved"] = v["alg"] * scale / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
+            v["frac"] = v["achieved"] / v["peak"]
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        d = kern[dom]
+        line["roofline"] = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                            "unit": d["unit"], "frac": d["frac"], "traffic": None,
+                            "avg_launch_ms": d["ms"]}
+        line["kernels"] = {k: {"ms": v["ms"], "bound": v["bound"], "achieved": v["achieved"],
+                               "unit": v["unit"], "frac": v["frac"]} for k, v in kern.items()}
+        line["kernels"]["form_z"] = {"ms": kt["form_z_ms"]}
+        line["kernels"]["backsub"] = {"ms": kt["backsub_ms"]}
+        line["kernels"]["lm_iteration_enqueued"] = {"ms": kt["lm_iteration_ms"]}
+        if not a.no_cpu_baseline:
+            from oracle import oracle as O
+            threads = min(os.cpu_count() or 1, 64)
+            sc = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                         s.obs_px)
+            t0 = time.perf_counter()
+            summ, _ = O.solve(sc, O.default_options(robustify=robust, num_threads=threads,
+                                                    linear_solver=O.SCHUR_AUTO))
+            dt = time.perf_counter() - t0
+            cpu_iters = summ["num_cost_evals"]   # one cost evaluation per LM iteration
+            line["cpu_baseline"] = {"value": cpu_iters / dt, "unit": "LM iterations/s", "cores": threads,
+                                    "kind": "port",
+                                    "sample": "one complete solve of the same workload (%d LM iterations, %.2f s) "
+                                              "by oracle/liboracle.so (C + OpenMP, Schur elimination of the same "
+                                              "family); Ceres itself is not installable here" % (cpu_iters, dt)}
+    ba.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

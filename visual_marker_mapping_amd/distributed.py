@@ -1,0 +1,78 @@
+"""One process per GPU: observation sharding and the all-reduce hook of the engine.
+
+The reference is single-process ("Parallelism strategies: none"); this is the
+MI355X side of BASELINE.json configs[2].  Observations are sharded by the ELIMINATED pose family
+(cameras by default: "observations shard naturally by camera"), every rank keeps all poses, and per
+LM iteration the ranks exchange by sum-all-reduce: the small normal-equation blocks after a Jacobian
+evaluation, the reduced system, the eliminated family's step and the candidate cost.
+"""
+import numpy as np
+
+
+def shard_bounds(counts, world_size):
+    """Splits poses 0..n-1 into world_size contiguous groups with balanced observation counts.
+
+    Returns an int array b of length world_size+1; rank r owns poses b[r] .. b[r+1]-1.
+    """
+    counts = np.asarray(counts, np.int64)
+    n = len(counts)
+    total = int(counts.sum())
+    bounds = [0]
+    acc, p = 0, 0
+    for r in range(1, world_size):
+        target = total * r / world_size
+        while p < n and acc + counts[p] / 2.0 <= target:
+            acc += int(counts[p])
+            p += 1
+        # leave at least one pose for every remaining rank when possible
+        p = min(p, max(bounds[-1], n - (world_size - r)))
+        p = max(p, min(bounds[-1] + 1, n))
+        bounds.append(p)
+    bounds.append(n)
+    return np.asarray(bounds, np.int64)
+
+
+def shard_observations(obs_cam, obs_tag, n_cams, n_tags, rank, world_size, eliminate_cameras=None):
+    """Index array of the observations rank `rank` owns (caller order preserved)."""
+    obs_cam = np.asarray(obs_cam)
+    obs_tag = np.asarray(obs_tag)
+    if eliminate_cameras is None:
+        eliminate_cameras = n_cams >= n_tags   # VMM_BA_ELIM_AUTO
+    key = obs_cam if eliminate_cameras else obs_tag
+    n = n_cams if eliminate_cameras else n_tags
+    counts = np.bincount(key, minlength=n)
+    b = shard_bounds(counts, world_size)
+    return np.nonzero((key >= b[rank]) & (key < b[rank + 1]))[0], bool(eliminate_cameras)
+
+
+class _DeviceBuffer:
+    """Zero-copy view of `count` doubles at a raw device pointer for torch.as_tensor."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False),
+                                         "version": 2}
+
+
+def make_allreduce(device_index, group=None):
+    """Returns fn(ptr, count, stream) for BundleAdjuster.set_allreduce using torch.distributed.
+
+    Backend nccl (= RCCL over xGMI): reduces the device buffer in place on the engine's stream.
+    Backend gloo (CPU tests, or several ranks sharing one GPU): stages through host memory.
+    """
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", device_index)
+
+    def fn(ptr, count, stream):
+        ext = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(ext):
+            t = torch.as_tensor(_DeviceBuffer(ptr, count), device=dev)
+            if backend == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                h = t.cpu()          # synchronises `ext`
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+    return fn
