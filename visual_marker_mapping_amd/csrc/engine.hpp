@@ -108,6 +108,7 @@ struct Engine {
     double* slabs = nullptr;        // [split_k][ldz*ldz]
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
     double* P = nullptr;            // [kNB][ldz] transposed Cholesky panel
+    double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
     double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)
     double* step_comm = nullptr;    // [6*n_e + 2]: delta of the eliminated family | cross term
     double* cost_comm = nullptr;    // [2] candidate cost (all-reduced)
@@ -118,6 +119,12 @@ struct Engine {
     LmCtl* ctl_host = nullptr;      // pinned
     vmm_ba_iteration* trace = nullptr;  // device
     int trace_capacity = 0;
+
+    // one LM iteration captured as a hipGraph (single GPU; collectives are host calls)
+    hipGraphExec_t iter_graph = nullptr;
+    int graph_robustify = -1;
+    double graph_huber_a = 0.0;
+    bool use_graph = true;
 
     std::vector<void*> allocs;
 };

@@ -11,148 +11,322 @@
 // thread per row, and also stores the panel transposed (P, 64 x ld) so that (2) the trailing update
 // A_ij -= L_ik L_jk^T is the same k-major MFMA f64 rank-k kernel that forms the Schur complement.
 // The back-substitution L^T y = w runs one small kernel per block, last block first.
+//
+// The 64x64 factorisation is latency-bound (64 dependent pivots), so it advances FOUR columns per
+// barrier round: every thread redundantly factors the 4x4 pivot block in registers (no barrier inside
+// the 4 dependent rsqrt chains), then the panel below is solved and the trailing block updated with a
+// rank-4 update.  The diagonal solve of the back-substitution uses the same 4-wide blocking.
 #include "engine.hpp"
 
 namespace vmm {
 
-void launch_syrk_raw(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, int row_blk0, int n_row_blk,
-                     int col_blk0, int n_col_blk, int split_k, int k_chunk, double* C, int ldc,
-                     size_t slab_stride, bool subtract);
+#ifdef VMM_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP(slot)                                                                  \
+    do {                                                                             \
+        if (blockIdx.x == 1 && threadIdx.x == 0 && k == 0) {                         \
+            g_stamps[slot] = __builtin_amdgcn_s_memtime();                           \
+            g_stamps[16 + slot] = __builtin_amdgcn_s_memrealtime();                  \
+        }                                                                            \
+    } while (0)
+#else
+#define STAMP(slot)
+#endif
+#ifdef VMM_STAMPS
+#define RSTAMP(slot)                                                                 \
+    do {                                                                             \
+        if (blockIdx.x == 1 && threadIdx.x == 0 && J0 == 32 && g_stamps[slot] == 0)  \
+            g_stamps[slot] = __builtin_amdgcn_s_memtime();                           \
+    } while (0)
+#else
+#define RSTAMP(slot)
+#endif
 
-constexpr int kLd = 65;  // LDS row stride of the 64x64 diagonal block (odd -> conflict-free columns)
+} // namespace vmm
+#include "potrf64.inc"
+namespace vmm {
 
-// Cholesky of the 64x64 block held in LDS (lower triangle, stride kLd), 256 threads.
-// invd[j] = 1 / L[j][j].  Returns false when a pivot is not positive.
-__device__ __forceinline__ bool potrf64_lds(double* A, double* invd)
+// Panel of block column k as ONE right-looking factorisation of the tall matrix [A_kk; A_ik]:
+// workgroup 0 owns only the diagonal block, workgroup b >= 1 the diagonal block (re-factored
+// redundantly, cheaper than a dependent launch) plus 64 rows below it (the rhs row n_pad is just one
+// more row).  Both 64x64 blocks live in v_mfma_f64_16x16x4_f64 accumulators for the whole kernel:
+// wave w holds the 16-row tile row w (tiles (w,0..3); for the diagonal block only tj <= w).
+// Sixteen rounds of four columns:
+//   1. the lanes that hold columns j0..j0+3 publish them to a small LDS panel buffer
+//   2. wave 0 (diagonal rows) and wave 1 (rows below) each factor the 4x4 pivot block in registers
+//      and scale "their" row: x = a L4^{-T}, written back in place
+//   3. every wave applies the rank-4 update C -= X X_d^T to its tiles with one MFMA per tile
+// The panel buffers ping-pong between rounds, so two barriers per round suffice and there is no
+// separate triangular-solve phase: after the last round the scaled columns ARE L_ik.
+constexpr int kPs = 5;   // LDS row stride (doubles) of the 64x4 panel buffers: conflict-free rows
+
+template <int J0, bool HAS_T>
+__device__ __forceinline__ void panel_round(const int w, const int lane,
+                                            double4_t (&Dacc)[4], double4_t (&Tacc)[4], double* __restrict__ Pd,
+                                            double* __restrict__ Pt, double* __restrict__ At,
+                                            double* __restrict__ R, double* __restrict__ invd, bool& ok)
 {
-    const int tid = threadIdx.x;
-    const int i = tid & 63, grp = tid >> 6;
-    bool ok = true;
-    for (int j = 0; j < 64; ++j) {
-        const double ajj = A[j * kLd + j];
-        const bool good = (ajj > 0.0) && isfinite(ajj);
-        ok = ok && good;
-        const double piv = good ? ajj : 1.0;
-        const double d = sqrt(piv);
-        const double inv = 1.0 / d;
-        double lij = 0.0;
-        if (i > j)
-            lij = A[i * kLd + j] * inv;
-        __syncthreads();  // everyone has read column j before it is overwritten
-        if (grp == 0) {
-            if (i > j)
-                A[i * kLd + j] = lij;
-            else if (i == j) {
-                A[j * kLd + j] = d;
-                invd[j] = inv;
-            }
+    constexpr int tc = J0 >> 4, cj = J0 & 15;
+    const int fr = lane & 15, fk = lane >> 4;
+    double* pd = Pd + ((J0 >> 2) & 1) * 64 * kPs;
+    double* pt = Pt + ((J0 >> 2) & 1) * 64 * kPs;
+    RSTAMP(6);
+    // 1. publish columns J0..J0+3 (rows of my tile row) from the accumulators
+    if (fr >= cj && fr < cj + 4) {
+        const int q = fr - cj;
+        const int row = 16 * w + fk;
+        if (w >= tc) {
+            pd[(row + 0) * kPs + q] = Dacc[tc][0];
+            pd[(row + 4) * kPs + q] = Dacc[tc][1];
+            pd[(row + 8) * kPs + q] = Dacc[tc][2];
+            pd[(row + 12) * kPs + q] = Dacc[tc][3];
         }
-        __syncthreads();
-        // trailing update: A[i][c] -= L[i][j] L[c][j] for j < c <= i; wave = column group
-        if (i > j) {
-            for (int c = j + 1 + grp; c <= i; c += 4)
-                A[i * kLd + c] -= lij * A[c * kLd + j];
+        if (HAS_T) {
+            pt[(row + 0) * kPs + q] = Tacc[tc][0];
+            pt[(row + 4) * kPs + q] = Tacc[tc][1];
+            pt[(row + 8) * kPs + q] = Tacc[tc][2];
+            pt[(row + 12) * kPs + q] = Tacc[tc][3];
         }
-        // no barrier needed here: the next iteration's reads of column j+1 happen after the
-        // barrier that follows them only for writes; keep a barrier for the RAW on A[.][j+1]
-        __syncthreads();
     }
-    return ok;
+    RSTAMP(7);
+    __syncthreads();
+    RSTAMP(8);
+    // 2. pivot block + row scaling (wave 0: diagonal rows, wave 1: rows below)
+    if (w == 0 || (w == 1 && HAS_T)) {
+        const double* D = pd + J0 * kPs;
+        double* row = (w == 0 ? pd : pt) + lane * kPs;
+        const double r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+        Piv4 p;
+        chol4(D[0], D[kPs], D[kPs + 1], D[2 * kPs], D[2 * kPs + 1], D[2 * kPs + 2], D[3 * kPs], D[3 * kPs + 1],
+              D[3 * kPs + 2], D[3 * kPs + 3], p);
+        const double x0 = r0 * p.i0;
+        const double x1 = (r1 - x0 * p.l10) * p.i1;
+        const double x2 = (r2 - x0 * p.l20 - x1 * p.l21) * p.i2;
+        const double x3 = (r3 - x0 * p.l30 - x1 * p.l31 - x2 * p.l32) * p.i3;
+        if (w == 0) {
+            ok = ok && p.ok;
+            const int r = lane - J0;
+            const bool below = r >= 4;
+            if (below) {
+                row[0] = x0; row[1] = x1; row[2] = x2; row[3] = x3;
+            }
+            if (!HAS_T) {
+                // keep L^T for the write-back: x below the pivot block, the factor inside, zero above
+                const bool above = r < 0;
+                At[(J0 + 0) * kLdT + lane] = below ? x0 : (above ? 0.0 : (r == 0 ? p.d0 : (r == 1 ? p.l10 : (r == 2 ? p.l20 : p.l30))));
+                At[(J0 + 1) * kLdT + lane] = below ? x1 : (above ? 0.0 : (r == 1 ? p.d1 : (r == 2 ? p.l21 : (r == 3 ? p.l31 : 0.0))));
+                At[(J0 + 2) * kLdT + lane] = below ? x2 : (above ? 0.0 : (r == 2 ? p.d2 : (r == 3 ? p.l32 : 0.0)));
+                At[(J0 + 3) * kLdT + lane] = below ? x3 : (above ? 0.0 : (r == 3 ? p.d3 : 0.0));
+                if (r >= 0 && r < 4)
+                    invd[lane] = r == 0 ? p.i0 : (r == 1 ? p.i1 : (r == 2 ? p.i2 : p.i3));
+            }
+        } else {
+            row[0] = x0; row[1] = x1; row[2] = x2; row[3] = x3;
+            double* rr = R + lane * kLd + J0;
+            rr[0] = x0; rr[1] = x1; rr[2] = x2; rr[3] = x3;
+        }
+    }
+    RSTAMP(9);
+    __syncthreads();
+    RSTAMP(10);
+    // 3. rank-4 update of the tiles right of the pivot columns.  MFMA f64 maps: A[i = lane&15][k = lane>>4],
+    //    B[k = lane>>4][j = lane&15], C row = (lane>>4) + 4*reg, col = lane&15.
+    if (J0 + 4 < 64) {
+        constexpr int t0 = (J0 + 4) >> 4;
+        const int ra = 16 * w + fr;
+        const double adv = pd[ra * kPs + fk];
+        const double ad = (ra >= J0 + 4) ? -adv : 0.0;
+        const double at = HAS_T ? -pt[ra * kPs + fk] : 0.0;
+        // the tile that holds the next pivot columns goes first: the next round's publish waits on it
+#pragma unroll
+        for (int tj = t0; tj < 4; ++tj) {
+            const int rb = 16 * tj + fr;
+            const double bv = pd[rb * kPs + fk];
+            const double b = (rb >= J0 + 4) ? bv : 0.0;
+            // tiles above the diagonal (tj > w) get a zero operand instead of a branch: straight-line code
+            const double adm = (tj <= w) ? ad : 0.0;
+            Dacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(adm, b, Dacc[tj], 0, 0, 0);
+            if (HAS_T)
+                Tacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, b, Tacc[tj], 0, 0, 0);
+        }
+    }
+    RSTAMP(11);
 }
 
-__global__ __launch_bounds__(256) void k_chol_panel(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad,
-                                                    int k, double* __restrict__ P)
+template <bool HAS_T>
+__device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
+                                           double* __restrict__ P, double* __restrict__ dinv, double* RA,
+                                           double* Pd, double* Pt, double* invd)
 {
-    if (ctl->done || ctl->lin_fail)
-        return;
-    __shared__ double A[64 * kLd];
-    __shared__ double invd[64];
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
     const int K0 = k * kNB;
-    // load the lower triangle of the diagonal block
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        A[r * kLd + c] = (c <= r) ? S[(int64_t)(K0 + r) * ld + K0 + c] : 0.0;
+    const int R0 = K0 + kNB + ((int)blockIdx.x - 1) * 64;
+    STAMP(0);
+    // accumulator-layout loads straight from global memory: for fixed (tile, reg) 16 lanes read 128
+    // contiguous bytes of one row
+    double4_t Dacc[4], Tacc[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+        Dacc[tj] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+        Tacc[tj] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * w + fk + 4 * r;
+            const double dv = S[(int64_t)(K0 + row) * ld + K0 + 16 * tj + fr];
+            Dacc[tj][r] = (tj <= w) ? dv : 0.0;
+            if (HAS_T) {
+                const int grow = (R0 + row <= n_pad) ? R0 + row : n_pad;   // clamp: always in bounds
+                const double tv = S[(int64_t)grow * ld + K0 + 16 * tj + fr];
+                Tacc[tj][r] = (R0 + row <= n_pad) ? tv : 0.0;
+            }
+        }
     }
+    STAMP(1);
+    bool ok = true;
+    panel_round<0, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<4, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<8, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<12, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<16, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<20, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<24, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<28, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<32, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<36, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<40, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<44, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<48, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<52, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<56, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
+    panel_round<60, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     __syncthreads();
-    const bool ok = potrf64_lds(A, invd);
-    if (blockIdx.x == 0) {
-        if (!ok && tid == 0)
+    STAMP(2);
+    if (!HAS_T) {
+        // `ok` is meaningful in wave 0 only
+        if (tid == 0 && !ok)
             ctl->lin_fail = 1;
+        if (tid < 64)
+            dinv[K0 + tid] = invd[tid];
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int r = idx >> 6, c = idx & 63;
             if (c <= r)
-                S[(int64_t)(K0 + r) * ld + K0 + c] = A[r * kLd + c];
+                S[(int64_t)(K0 + r) * ld + K0 + c] = RA[c * kLdT + r];
         }
         return;
     }
-    // rows below the diagonal block, including the rhs row n_pad
-    const int row = K0 + kNB + (blockIdx.x - 1) * 256 + tid;
-    if (row > n_pad)
-        return;
-    double x[64];
-    double* srow = S + (int64_t)row * ld + K0;
-#pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(srow + c);
-        x[c] = v.x;
-        x[c + 1] = v.y;
+    STAMP(4);
+    // L_ik = the scaled columns collected in R: coalesced stores to S and, transposed, to P
+    const double* R = RA;
+    for (int idx = tid; idx < 64 * 32; idx += 256) {
+        const int rr = idx >> 5, c = (idx & 31) * 2;
+        if (R0 + rr <= n_pad)
+            *reinterpret_cast<double2*>(S + (int64_t)(R0 + rr) * ld + K0 + c)
+                = make_double2(R[rr * kLd + c], R[rr * kLd + c + 1]);
     }
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        double s = x[j];
-#pragma unroll
-        for (int m = 0; m < j; ++m)
-            s -= x[m] * A[j * kLd + m];
-        x[j] = s * invd[j];
+    {
+        const int rr = tid & 63;
+        if (R0 + rr <= n_pad)
+            for (int c = tid >> 6; c < 64; c += 4)
+                P[(int64_t)c * ld + R0 + rr] = R[rr * kLd + c];
     }
-#pragma unroll
-    for (int c = 0; c < 64; c += 2)
-        *reinterpret_cast<double2*>(srow + c) = make_double2(x[c], x[c + 1]);
-#pragma unroll
-    for (int c = 0; c < 64; ++c)
-        P[(int64_t)c * ld + row] = x[c];
+    STAMP(5);
 }
 
-// One step of L^T y = w (w lives in row n_pad of S).  Launched for kb = n_blk-1 .. 0 with kb+1
-// workgroups of 64 threads: workgroup m first applies y_{kb+1} to w_m, then workgroup kb solves its
-// diagonal block.
-__global__ __launch_bounds__(64) void k_backsolve_step(const LmCtl* ctl, double* __restrict__ S, int ld,
-                                                       int n_pad, int n_blk, int kb, double* __restrict__ y)
+__global__ __launch_bounds__(256) void k_chol_panel(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad,
+                                                    int k, double* __restrict__ P, double* __restrict__ dinv)
 {
     if (ctl->done || ctl->lin_fail)
         return;
+    __shared__ double RA[64 * kLdT];   // workgroup 0: L^T (stride kLdT); others: result tile R (stride kLd)
+    __shared__ double Pd[2 * 64 * kPs];
+    __shared__ double Pt[2 * 64 * kPs];
+    __shared__ double invd[64];
+    if (blockIdx.x == 0)
+        panel_body<false>(ctl, S, ld, n_pad, k, P, dinv, RA, Pd, Pt, invd);
+    else
+        panel_body<true>(ctl, S, ld, n_pad, k, P, dinv, RA, Pd, Pt, invd);
+}
+
+#ifdef VMM_STAMPS
+extern "C" int vmm_ba_debug_read_stamps(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 32 ? n : 32));
+}
+#endif
+
+// One step of L^T y = w (w lives in row n_pad of S).  Launched for kb = n_blk-1 .. 0 with kb+1
+// workgroups of 256 threads: workgroup m first applies y_{kb+1} to w_m (64x64 transposed GEMV split
+// over the four waves), then workgroup kb solves its diagonal block four unknowns per round.
+__global__ __launch_bounds__(256) void k_backsolve_step(const LmCtl* ctl, double* __restrict__ S, int ld,
+                                                        int n_pad, int n_blk, int kb, double* __restrict__ y,
+                                                        const double* __restrict__ dinv)
+{
+    if (ctl->done || ctl->lin_fail)
+        return;
+    __shared__ double red[4][64];
+    __shared__ double L[64 * kLd];
+    __shared__ double ws[64];
+    __shared__ double di[64];
     const int m = blockIdx.x;
-    const int c = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int c = tid & 63, part = tid >> 6;
     double* w = S + (int64_t)n_pad * ld;
-    double wc = w[m * kNB + c];
+    double wc = 0.0;
     if (kb + 1 < n_blk) {
-        const int R0 = (kb + 1) * kNB;
+        const int R0 = (kb + 1) * kNB + part * 16;
         const double* Lb = S + (int64_t)R0 * ld + m * kNB + c;
         double acc = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
             acc += Lb[(int64_t)r * ld] * y[R0 + r];
-        wc -= acc;
-        w[m * kNB + c] = wc;
+        red[part][c] = acc;
+    }
+    if (m == kb) {
+        // stage the diagonal block while the partial sums settle
+        const int K0 = kb * kNB;
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int r = idx >> 6, cc = idx & 63;
+            L[r * kLd + cc] = (cc <= r) ? S[(int64_t)(K0 + r) * ld + K0 + cc] : 0.0;
+        }
+        if (tid < 64)
+            di[tid] = dinv[K0 + tid];
+    }
+    __syncthreads();
+    if (part == 0) {
+        wc = w[m * kNB + c];
+        if (kb + 1 < n_blk) {
+            wc -= (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            w[m * kNB + c] = wc;
+        }
     }
     if (m != kb)
         return;
-    __shared__ double L[64 * kLd];
-    const int K0 = kb * kNB;
-    for (int r = 0; r < 64; ++r)
-        L[r * kLd + c] = (c <= r) ? S[(int64_t)(K0 + r) * ld + K0 + c] : 0.0;
-    __syncthreads();
+    // single wave from here on (part == 0); other waves only keep the barriers company
     double yj = 0.0;
-    for (int j = 63; j >= 0; --j) {
-        const double wj = __shfl(wc, j, 64);
-        const double v = wj / L[j * kLd + j];
-        if (c == j)
-            yj = v;
-        if (c < j)
-            wc -= L[j * kLd + c] * v;
+    for (int j0 = 60; j0 >= 0; j0 -= 4) {
+        if (part == 0)
+            ws[c] = wc;
+        __syncthreads();
+        if (part == 0) {
+            // L4^T v = w4 with L4 the lower 4x4 pivot block at (j0, j0)
+            const double* D = L + j0 * kLd + j0;
+            const double v3 = ws[j0 + 3] * di[j0 + 3];
+            const double v2 = (ws[j0 + 2] - D[3 * kLd + 2] * v3) * di[j0 + 2];
+            const double v1 = (ws[j0 + 1] - D[2 * kLd + 1] * v2 - D[3 * kLd + 1] * v3) * di[j0 + 1];
+            const double v0 = (ws[j0] - D[kLd] * v1 - D[2 * kLd] * v2 - D[3 * kLd] * v3) * di[j0];
+            if (c >= j0 && c < j0 + 4)
+                yj = (c == j0) ? v0 : (c == j0 + 1 ? v1 : (c == j0 + 2 ? v2 : v3));
+            if (c < j0)
+                wc -= L[j0 * kLd + c] * v0 + L[(j0 + 1) * kLd + c] * v1 + L[(j0 + 2) * kLd + c] * v2
+                    + L[(j0 + 3) * kLd + c] * v3;
+        }
+        __syncthreads();
     }
-    y[K0 + c] = yj;
+    if (part == 0)
+        y[kb * kNB + c] = yj;
 }
 
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl)
@@ -160,15 +334,15 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
     const int n_blk = n_pad / kNB;
     for (int k = 0; k < n_blk; ++k) {
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
-        const int wgs = 1 + (rows_below + 255) / 256;
-        hipLaunchKernelGGL(k_chol_panel, dim3(wgs), dim3(256), 0, e.stream, ctl, S, ld, n_pad, k, e.P);
+        const int wgs = 1 + (rows_below + 63) / 64;
+        hipLaunchKernelGGL(k_chol_panel, dim3(wgs), dim3(256), 0, e.stream, ctl, S, ld, n_pad, k, e.P, e.dinv);
         // trailing update on block rows k+1..n_blk (rhs row block included), block cols k+1..n_blk-1
         if (k + 1 < n_blk)
             launch_syrk_raw(e.stream, ctl, e.P, ld, k + 1, n_blk - k, k + 1, n_blk - 1 - k, 1, kNB, S, ld, 0,
                             true);
     }
     for (int kb = n_blk - 1; kb >= 0; --kb)
-        hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(64), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y);
+        hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y, e.dinv);
 }
 
 } // namespace vmm

@@ -5,6 +5,7 @@
 // ceres::Problem construction (:657-724), vmm_ba_solve() of ceres::Solve (:737-738).  No CPU
 // fallback exists: without a HIP device every entry point fails with VMM_BA_ERR_HIP.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -128,6 +129,8 @@ static void destroy_engine(Engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream)
         (void)hipStreamSynchronize(e->stream);
+    if (e->iter_graph)
+        (void)hipGraphExecDestroy(e->iter_graph);
     for (void* p : e->allocs)
         (void)hipFree(p);
     if (e->ctl_host)
@@ -161,6 +164,42 @@ static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
     if ((rc = do_allreduce(e, e.cost_comm, 1))) return rc;
     launch_decide(e);
     HIP_TRY(hipGetLastError());
+    return VMM_BA_OK;
+}
+
+// Single GPU: the iteration is captured once into a hipGraph and replayed (about 75 small launches;
+// eager enqueueing is host-bound).  With world > 1 the all-reduce callbacks are host calls, so the
+// sequence is enqueued eagerly.
+static int run_iteration(Engine& e, const vmm_ba_options& o)
+{
+    if (e.world > 1 || !e.use_graph)
+        return enqueue_iteration(e, o);
+    if (!e.iter_graph || e.graph_robustify != o.robustify || e.graph_huber_a != o.huber_a) {
+        if (e.iter_graph) {
+            (void)hipGraphExecDestroy(e.iter_graph);
+            e.iter_graph = nullptr;
+        }
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_iteration(e, o);
+        const hipError_t ee = hipStreamEndCapture(e.stream, &g);
+        if (rc)
+            return rc;
+        if (ee != hipSuccess || !g) {
+            set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+            return VMM_BA_ERR_HIP;
+        }
+        const hipError_t ei = hipGraphInstantiate(&e.iter_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ei != hipSuccess) {
+            e.iter_graph = nullptr;
+            set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+            return VMM_BA_ERR_HIP;
+        }
+        e.graph_robustify = o.robustify;
+        e.graph_huber_a = o.huber_a;
+    }
+    HIP_TRY(hipGraphLaunch(e.iter_graph, e.stream));
     return VMM_BA_OK;
 }
 
@@ -286,6 +325,10 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     }
     e.rank = co.rank;
     e.world = co.world_size;
+    {
+        const char* ng = getenv("VMM_BA_NO_GRAPH");
+        e.use_graph = !(ng && ng[0] == '1');
+    }
     e.K.fx = p->intr[0]; e.K.fy = p->intr[1]; e.K.cx = p->intr[2]; e.K.cy = p->intr[3];
     e.K.k1 = p->dist[0]; e.K.k2 = p->dist[1]; e.K.p1 = p->dist[2]; e.K.p2 = p->dist[3]; e.K.k3 = p->dist[4];
     e.n_cams = p->n_cams;
@@ -371,6 +414,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.slabs, (size_t)e.split_k * e.ldz * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.P, (size_t)kNB * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.step_comm, (size_t)6 * e.n_e + 2))) return fail(rc);
     if ((rc = dev_alloc(e, &e.cost_comm, 2))) return fail(rc);
@@ -469,6 +513,10 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
         int rc;
         if ((rc = dev_alloc(e, &e.trace, (size_t)need_cap, false))) return rc;
         e.trace_capacity = need_cap;
+        if (e.iter_graph) {   // the captured k_lm_begin holds the old trace pointer
+            (void)hipGraphExecDestroy(e.iter_graph);
+            e.iter_graph = nullptr;
+        }
     }
     init_ctl(*e.ctl_host, o, user_cap);
     HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
@@ -479,7 +527,7 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
     for (;;) {
         int rc;
         for (int k = 0; k < poll && enq < max_steps; ++k, ++enq)
-            if ((rc = enqueue_iteration(e, o))) return rc;
+            if ((rc = run_iteration(e, o))) return rc;
         HIP_TRY(hipMemcpyAsync(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream));
         HIP_TRY(hipStreamSynchronize(e.stream));
         if (e.ctl_host->done)
@@ -671,6 +719,7 @@ static int make_scratch(Engine& e, int device, int ld)
     HIP_TRY(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
     int rc;
     if ((rc = dev_alloc(e, &e.P, (size_t)kNB * ld))) return rc;
+    if ((rc = dev_alloc(e, &e.dinv, (size_t)ld + kNB))) return rc;
     if ((rc = dev_alloc(e, &e.ctl, 1))) return rc;
     return VMM_BA_OK;
 }
@@ -804,6 +853,10 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     if (e.trace_capacity < 1) {
         if ((rc = dev_alloc(e, &e.trace, 1, false))) return rc;
         e.trace_capacity = 1;
+        if (e.iter_graph) {
+            (void)hipGraphExecDestroy(e.iter_graph);
+            e.iter_graph = nullptr;
+        }
     }
     vmm_ba_options ot = o;
     ot.max_num_iterations = 1 << 30;
@@ -857,7 +910,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
     HIP_TRY(hipEventRecord(ev0, e.stream));
     for (int r = 0; r < reps; ++r)
-        if ((rc = enqueue_iteration(e, ot))) return rc;
+        if ((rc = run_iteration(e, ot))) return rc;
     HIP_TRY(hipEventRecord(ev1, e.stream));
     HIP_TRY(hipEventSynchronize(ev1));
     float ms = 0.f;
