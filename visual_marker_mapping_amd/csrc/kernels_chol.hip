@@ -257,6 +257,81 @@ extern "C" int vmm_ba_debug_read_stamps(unsigned long long* out, int n)
 }
 #endif
 
+// Trailing update of block column k: A_ij -= L_ik L_jk^T for k < j <= i (the rhs row block included)
+// with K = 64 taken from the transposed panel P (64 x ld, row m = panel column m).  One workgroup per
+// 64x64 tile; the whole K extent of both operands (2 x 32 KB) and the C tile are requested up front
+// so the kernel pays one memory latency, then 16 k-steps of four v_mfma_f64_16x16x4_f64 per wave.
+__global__ __launch_bounds__(256) void k_chol_update(const LmCtl* ctl, double* __restrict__ S, int ld, int n_blk,
+                                                     int k, const double* __restrict__ P)
+{
+    if (ctl->done || ctl->lin_fail)
+        return;
+    __shared__ __attribute__((aligned(16))) double As[64 * kLdsRow];
+    __shared__ __attribute__((aligned(16))) double Bs[64 * kLdsRow];
+    // tile index -> (bi, bj): rows k+1..n_blk, columns k+1..min(bi, n_blk-1)
+    int t = blockIdx.x, bi = k + 1, bj = k + 1;
+    for (int r = k + 1; r <= n_blk; ++r) {
+        const int cnt = ((r < n_blk) ? r : n_blk - 1) - k;
+        if (t < cnt) {
+            bi = r;
+            bj = k + 1 + t;
+            break;
+        }
+        t -= cnt;
+    }
+    const int I0 = bi * kNB, J0 = bj * kNB;
+    const bool diag = bi == bj;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int fk = lane >> 4, fi = lane & 15;
+    double2 va[8], vb[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 256 + tid;
+        const int m = idx >> 5, c = (idx & 31) * 2;
+        va[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + I0 + c);
+        vb[it] = diag ? va[it] : *reinterpret_cast<const double2*>(P + (int64_t)m * ld + J0 + c);
+    }
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[a][b][r] = S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 256 + tid;
+        const int m = idx >> 5, c = (idx & 31) * 2;
+        *reinterpret_cast<double2*>(&As[m * kLdsRow + c]) = va[it];
+        if (!diag)
+            *reinterpret_cast<double2*>(&Bs[m * kLdsRow + c]) = vb[it];
+    }
+    __syncthreads();
+    const double* Bp = diag ? As : Bs;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int row = (ks * 4 + fk) * kLdsRow;
+        const double a0 = -As[row + wi * 32 + fi];
+        const double a1 = -As[row + wi * 32 + 16 + fi];
+        const double b0 = Bp[row + wj * 32 + fi];
+        const double b1 = Bp[row + wj * 32 + 16 + fi];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi] = acc[a][b][r];
+}
+
 // One step of L^T y = w (w lives in row n_pad of S).  Launched for kb = n_blk-1 .. 0 with kb+1
 // workgroups of 256 threads: workgroup m first applies y_{kb+1} to w_m (64x64 transposed GEMV split
 // over the four waves), then workgroup kb solves its diagonal block four unknowns per round.
@@ -337,9 +412,12 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         const int wgs = 1 + (rows_below + 63) / 64;
         hipLaunchKernelGGL(k_chol_panel, dim3(wgs), dim3(256), 0, e.stream, ctl, S, ld, n_pad, k, e.P, e.dinv);
         // trailing update on block rows k+1..n_blk (rhs row block included), block cols k+1..n_blk-1
-        if (k + 1 < n_blk)
-            launch_syrk_raw(e.stream, ctl, e.P, ld, k + 1, n_blk - k, k + 1, n_blk - 1 - k, 1, kNB, S, ld, 0,
-                            true);
+        if (k + 1 < n_blk) {
+            int tiles = 0;
+            for (int r = k + 1; r <= n_blk; ++r)
+                tiles += ((r < n_blk) ? r : n_blk - 1) - k;
+            hipLaunchKernelGGL(k_chol_update, dim3(tiles), dim3(256), 0, e.stream, ctl, S, ld, n_blk, k, e.P);
+        }
     }
     for (int kb = n_blk - 1; kb >= 0; --kb)
         hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y, e.dinv);
