@@ -1,0 +1,66 @@
+"""Two ranks (one process each, both on the single test GPU, gloo for the exchange) must follow the
+same LM trajectory as one rank: the sharded engine path with its four all-reduces per iteration."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out, elim):
+    import torch
+    import torch.distributed as dist
+    from visual_marker_mapping_amd import distributed as vd
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    s = make_scene(1, visibility=0.7)
+    elim_cams = (elim == "cams")
+    idx, _ = vd.shard_observations(s.obs_cam, s.obs_tag, len(s.cam_init), len(s.tag_init), rank, world, elim_cams)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam[idx],
+                            s.obs_tag[idx], s.obs_px[idx], device=0,
+                            elimination=eng.ELIM_CAMERAS if elim_cams else eng.ELIM_TAGS, rank=rank, world_size=world)
+    ba.set_allreduce(vd.make_allreduce(0))
+    out_s = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+    cam, tag = ba.get_state()
+    cost = ba.cost(robustify=True)
+    ba.close()
+    np.savez(out % rank, cam=cam, tag=tag, iters=out_s["iterations"], final=out_s["final_cost"], cost=cost,
+             costs=[t["cost"] for t in out_s["trace"]])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("elim", ["cams", "tags"])
+def test_two_ranks_match_one_rank(tmp_path, elim):
+    mp = pytest.importorskip("torch.multiprocessing")
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out, elim), nprocs=2, join=True)
+    s = make_scene(1, visibility=0.7)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                            s.obs_px, elimination=eng.ELIM_CAMERAS if elim == "cams" else eng.ELIM_TAGS)
+    ref = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+    cam, tag = ba.get_state()
+    ba.close()
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    # both ranks hold the same full state, equal to the single-rank result (<= 1e-12 rel.)
+    np.testing.assert_array_equal(r0["cam"], r1["cam"])
+    np.testing.assert_array_equal(r0["tag"], r1["tag"])
+    assert int(r0["iters"]) == ref["iterations"]
+    np.testing.assert_allclose(r0["costs"], [t["cost"] for t in ref["trace"]], rtol=1e-10)
+    np.testing.assert_allclose(r0["cam"], cam, rtol=0, atol=1e-10 * np.abs(cam).max())
+    np.testing.assert_allclose(r0["tag"], tag, rtol=0, atol=1e-10 * np.abs(tag).max())
+    np.testing.assert_allclose(float(r0["cost"]), float(r0["final"]), rtol=1e-12)

@@ -1,0 +1,94 @@
+"""GPU tests of the TagReconstructor mirror (reference API names) against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(s, tag_ids, cam_ids):
+    from visual_marker_mapping_amd import tag_reconstructor as tr
+    det = tr.DetectionResult(
+        [tr.TagImg(cid, "i%d.jpg" % cid) for cid in cam_ids],
+        [tr.Tag(tid, "apriltag_36h11", *s.tag_wh[k]) for k, tid in enumerate(tag_ids)],
+        [tr.TagObservation(cam_ids[c], tag_ids[t], px.reshape(4, 2)) for c, t, px in zip(s.obs_cam, s.obs_tag, s.obs_px)])
+    rec = tr.TagReconstructor(det)
+    rec.setCameraModel(tr.CameraModel(*s.intr, s.dist, 4000, 6000))
+    rec.setReconstructedTags({tid: tr.ReconstructedTag(tid, "apriltag_36h11", s.tag_init[k, :4], s.tag_init[k, 4:],
+                                                        *s.tag_wh[k]) for k, tid in enumerate(tag_ids)})
+    rec.setReconstructedCameras({cid: tr.Camera(cid, s.cam_init[k, :4], s.cam_init[k, 4:])
+                                 for k, cid in enumerate(cam_ids)})
+    rec.setOriginTagId(tag_ids[0])
+    return rec
+
+
+def test_do_bundle_adjustment_matches_oracle_with_sparse_ids(oracle, capsys):
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1)
+    tag_ids = [230 + 3 * k for k in range(len(s.tag_init))]
+    cam_ids = [1000 - 7 * k for k in range(len(s.cam_init))]      # descending: map order != array order
+    rec = _make(s, tag_ids, cam_ids)
+    rec.doBundleAdjustment(400, 4, True, False)
+    assert "Solution 0" in capsys.readouterr().out                 # src/TagReconstructor.cpp:740
+    sc = oracle.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px)
+    summ, _ = oracle.solve(sc, oracle.default_options(robustify=1, linear_solver=oracle.DENSE_NORMAL))
+    assert rec.lastSummary["iterations"] == summ["iterations"]
+    for k, cid in enumerate(cam_ids):
+        np.testing.assert_allclose(np.r_[rec.reconstructedCameras[cid].q, rec.reconstructedCameras[cid].t],
+                                   sc.cam_qt[k], rtol=0, atol=1e-6 * np.abs(sc.cam_qt).max())
+    for k, tid in enumerate(tag_ids):
+        np.testing.assert_allclose(np.r_[rec.reconstructedTags[tid].q, rec.reconstructedTags[tid].t],
+                                   sc.tag_qt[k], rtol=0, atol=1e-6 * np.abs(sc.tag_qt).max())
+    # the origin tag is constant (src/TagReconstructor.cpp:669-673)
+    np.testing.assert_array_equal(rec.reconstructedTags[tag_ids[0]].t, s.tag_init[0, 4:])
+
+
+def test_reprojection_statistics_and_pruning(oracle, capsys):
+    from visual_marker_mapping_amd import tag_reconstructor as tr
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1)
+    tag_ids = list(range(10, 10 + len(s.tag_init)))
+    cam_ids = list(range(len(s.cam_init)))
+    rec = _make(s, tag_ids, cam_ids)
+    rec.doBundleAdjustment(400, 1, True)
+    sc = oracle.Scene(s.intr, s.dist, [np.r_[rec.reconstructedCameras[c].q, rec.reconstructedCameras[c].t] for c in cam_ids],
+                      [np.r_[rec.reconstructedTags[t].q, rec.reconstructedTags[t].t] for t in tag_ids],
+                      s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px)
+    pc, pt, avg, corner = oracle.reprojection_stats(sc)
+    per_img = rec.computeReprojectionErrorPerImg()
+    per_tag, gavg = rec.computeReprojectionErrorPerTag()
+    per_corner = rec.computeReprojectionErrorPerCorner()
+    np.testing.assert_allclose([per_img[c] for c in cam_ids], pc, rtol=1e-11)
+    np.testing.assert_allclose([per_tag[t] for t in tag_ids], pt, rtol=1e-11)
+    assert abs(gavg - avg) < 1e-11 * avg
+    np.testing.assert_allclose(np.array(per_corner), corner.reshape(-1, 2), rtol=0, atol=1e-9)
+    assert max(per_tag.values()) < 2.0
+    # nothing to prune at 0.3 px noise ...
+    rec.removeBadMarkers(2.0)
+    rec.removeBadCameras(2.0)
+    assert len(rec.reconstructedTags) == len(tag_ids) and len(rec.reconstructedCameras) == len(cam_ids)
+    # ... a displaced tag and a displaced camera are pruned, the origin tag never is (:792-799)
+    rec.reconstructedTags[tag_ids[3]].t += 0.05
+    rec.reconstructedTags[tag_ids[0]].t += 0.05
+    rec.removeBadMarkers(2.0)
+    assert tag_ids[3] not in rec.reconstructedTags and tag_ids[0] in rec.reconstructedTags
+    rec.reconstructedTags[tag_ids[0]].t -= 0.05
+    rec.reconstructedCameras[cam_ids[5]].t += 0.2
+    # a reconstructed camera without any observation of a reconstructed tag gets -1 and is removed (:379-383, :809)
+    rec.reconstructedCameras[999] = tr.Camera(999)
+    assert rec.computeReprojectionErrorPerImg()[999] == -1.0
+    rec.removeBadCameras(2.0)
+    assert cam_ids[5] not in rec.reconstructedCameras and 999 not in rec.reconstructedCameras
+    out = capsys.readouterr().out
+    assert "Removing bad marker with id %d" % tag_ids[3] in out and "Removing bad camera with id 999" in out
+    # BA still runs on the pruned problem
+    rec.doBundleAdjustment(400, 1, False)
+    assert rec.lastSummary["termination_type"] == 0
+
+
+def test_project_point_is_camera_model_project_point(oracle, kats):
+    from visual_marker_mapping_amd import tag_reconstructor as tr
+    case = kats["obs"][1]
+    cm = tr.CameraModel(*case["intr"], case["dist"])
+    p = np.array([0.3, -0.2, 2.5])
+    np.testing.assert_allclose(cm.projectPoint(p), oracle.project_point(case["intr"], case["dist"], p), atol=1e-9)
+    assert cm.projectPoint(np.tile(p, (5, 1))).shape == (5, 2)

@@ -1,0 +1,154 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/vmm_ba.h declares, it refuses to
+run without a GPU (no silent CPU fallback), and the host-side packing/sharding logic is right."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    from visual_marker_mapping_amd import _lib
+    header = open(os.path.join(ROOT, "include", "vmm_ba.h")).read()
+    declared = set(re.findall(r"\b(vmm_ba_[a-z_]+)\s*\(", header))
+    declared -= {"vmm_ba_allreduce_fn"}
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) == declared
+    assert L.vmm_ba_abi_version() == 1
+
+
+def test_default_options_are_the_ceres_defaults_the_reference_runs_with():
+    from visual_marker_mapping_amd import engine
+    o = engine.default_options()
+    assert o.max_num_iterations == 400 and o.robustify == 1 and o.huber_a == 1.0
+    assert (o.function_tolerance, o.gradient_tolerance, o.parameter_tolerance) == (1e-6, 1e-10, 1e-8)
+    assert (o.initial_trust_region_radius, o.max_trust_region_radius, o.min_trust_region_radius) == (1e4, 1e16, 1e-32)
+    assert (o.min_relative_decrease, o.min_lm_diagonal, o.max_lm_diagonal) == (1e-3, 1e-6, 1e32)
+    assert o.max_num_consecutive_invalid_steps == 5 and o.jacobi_scaling == 1
+    with pytest.raises(AttributeError):
+        engine.default_options(no_such_option=1)
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the behaviour WITHOUT a GPU")
+def test_no_gpu_means_loud_failure_not_a_cpu_fallback():
+    from visual_marker_mapping_amd import _lib, engine
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1)
+    with pytest.raises(_lib.VmmBaError) as ei:
+        engine.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px)
+    assert ei.value.status == _lib.ERR_HIP
+    with pytest.raises(_lib.VmmBaError):
+        engine.project_points(s.intr, s.dist, np.ones((2, 3)))
+
+
+def test_argument_validation_happens_before_touching_the_device():
+    from visual_marker_mapping_amd import _lib, engine
+    with pytest.raises(_lib.VmmBaError) as ei:   # observation references camera 3 of 1
+        engine.BundleAdjuster([1, 1, 0, 0], [0] * 5, [[1, 0, 0, 0, 0, 0, 1]], [[1, 0, 0, 0, 0, 0, 0]], [[0.1, 0.1]],
+                              0, [3], [0], [[0] * 8])
+    assert ei.value.status == _lib.ERR_ARGUMENT
+    with pytest.raises(ValueError):
+        engine.BundleAdjuster([1, 1, 0, 0], [0] * 5, [[1, 0, 0, 0, 0, 0, 1]], [[1, 0, 0, 0, 0, 0, 0]], [[0.1, 0.1]],
+                              0, [0, 0], [0], [[0] * 8])
+
+
+def _reconstructor(s, tag_ids, cam_ids):
+    from visual_marker_mapping_amd import tag_reconstructor as tr
+    det = tr.DetectionResult(
+        [tr.TagImg(cid, "i%d.jpg" % cid) for cid in cam_ids],
+        [tr.Tag(tid, "apriltag_36h11", *s.tag_wh[k]) for k, tid in enumerate(tag_ids)],
+        [tr.TagObservation(cam_ids[c], tag_ids[t], px.reshape(4, 2)) for c, t, px in zip(s.obs_cam, s.obs_tag, s.obs_px)])
+    rec = tr.TagReconstructor(det)
+    rec.setCameraModel(tr.CameraModel(*s.intr, s.dist, 4000, 6000))
+    rec.setReconstructedTags({tid: tr.ReconstructedTag(tid, "apriltag_36h11", s.tag_init[k, :4], s.tag_init[k, 4:],
+                                                        *s.tag_wh[k]) for k, tid in enumerate(tag_ids)})
+    rec.setReconstructedCameras({cid: tr.Camera(cid, s.cam_init[k, :4], s.cam_init[k, 4:])
+                                 for k, cid in enumerate(cam_ids)})
+    rec.setOriginTagId(tag_ids[0])
+    return rec
+
+
+def test_pack_follows_the_reference_problem_assembly():
+    """src/TagReconstructor.cpp:663-724: map (id) order, cameras without reconstructed tags dropped,
+    observations of unreconstructed tags/cameras dropped, origin tag -> fixed index."""
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=5, n_tags=4)
+    tag_ids, cam_ids = [230, 7, 19, 8], [40, 10, 30, 20, 50]     # deliberately unsorted, non-dense ids
+    rec = _reconstructor(s, tag_ids, cam_ids)
+    del rec.reconstructedTags[19]                                 # an unreconstructed tag
+    del rec.reconstructedCameras[30]                              # an unreconstructed camera
+    p = rec._pack(for_ba=True)
+    assert p["tag_ids"] == [7, 8, 230] and p["cam_ids"] == [10, 20, 40, 50]
+    assert p["fixed"] == 2                                        # origin 230 is the last in map order
+    n_expected = sum(1 for c, t in zip(s.obs_cam, s.obs_tag) if cam_ids[c] != 30 and tag_ids[t] != 19)
+    assert len(p["obs_cam"]) == n_expected == len(p["obs_px"])
+    # every kept observation points at the right pose rows
+    k = 0
+    for c, t, px in zip(s.obs_cam, s.obs_tag, s.obs_px):
+        if cam_ids[c] == 30 or tag_ids[t] == 19:
+            continue
+        assert p["cam_ids"][p["obs_cam"][k]] == cam_ids[c] and p["tag_ids"][p["obs_tag"][k]] == tag_ids[t]
+        np.testing.assert_array_equal(p["obs_px"][k], px)
+        k += 1
+    # a camera that only sees unreconstructed tags is not part of the BA problem (:689-690)
+    for tid in (7, 8):
+        del rec.reconstructedTags[tid]
+    rec.detectionResults_.tagObservations = [o for o in rec.detectionResults_.tagObservations
+                                             if not (o.imageId == 10 and o.tagId == 230)]
+    p = rec._pack(for_ba=True)
+    assert 10 not in p["cam_ids"]
+    assert 10 in rec._pack(for_ba=False)["cam_ids"]               # but it still gets a (-1) statistic
+
+
+def test_tag_quad_and_getters_match_reference_definitions():
+    from visual_marker_mapping_amd import tag_reconstructor as tr
+    t = tr.ReconstructedTag(3, "x", [1, 0, 0, 0], [1, 2, 3], 0.2, 0.1)
+    loc = np.array(t.computeLocalMarkerCorners3D())
+    np.testing.assert_allclose(loc, [[-0.1, -0.05, 0], [0.1, -0.05, 0], [0.1, 0.05, 0], [-0.1, 0.05, 0]])
+    np.testing.assert_allclose(np.array(t.computeMarkerCorners3D()), loc + [1, 2, 3])
+    cm = tr.CameraModel(10, 20, 3, 4)
+    np.testing.assert_array_equal(cm.getK(), [[10, 0, 3], [0, 20, 4], [0, 0, 1]])
+    rec = tr.TagReconstructor(tr.DetectionResult([], [tr.Tag(9, "a", 1, 1), tr.Tag(4, "a", 1, 1)], []))
+    assert rec.getLowestTag() == 4 and rec.originTagId == -1
+    with pytest.raises(RuntimeError):
+        rec.moveTagIntoOrigin(4)
+    with pytest.raises(NotImplementedError):
+        rec.startReconstruction()
+
+
+def test_shard_bounds_cover_and_balance():
+    from visual_marker_mapping_amd import distributed as d
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        for counts in (np.full(500, 200), rng.integers(0, 50, 37), np.array([5, 0, 0, 100, 1, 1, 1, 1])):
+            b = d.shard_bounds(counts, world)
+            assert b[0] == 0 and b[-1] == len(counts) and np.all(np.diff(b) >= 0) and len(b) == world + 1
+            loads = [counts[b[r]:b[r + 1]].sum() for r in range(world)]
+            assert sum(loads) == counts.sum()
+            if counts.max() * 4 < counts.sum() / world:
+                assert max(loads) <= 1.3 * counts.sum() / world
+    idx_all = []
+    oc, ot = rng.integers(0, 20, 300), rng.integers(0, 10, 300)
+    for r in range(4):
+        idx, elim_cams = d.shard_observations(oc, ot, 20, 10, r, 4)
+        assert elim_cams
+        idx_all.append(idx)
+    np.testing.assert_array_equal(np.sort(np.concatenate(idx_all)), np.arange(300))
+    # a camera's observations never straddle two ranks
+    owners = {}
+    for r, idx in enumerate(idx_all):
+        for c in set(oc[idx]):
+            assert owners.setdefault(c, r) == r

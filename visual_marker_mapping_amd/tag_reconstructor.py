@@ -1,0 +1,337 @@
+"""Host-side mirror of the reference's TagReconstructor / CameraModel interface for the hot path.
+
+Same names, argument meaning and error behaviour as
+/root/reference/include/visual_marker_mapping/{TagReconstructor,CameraModel,Camera,DetectionResults}.h,
+so that the parity tests read like tests of the reference class.  The bodies of the hot-path methods
+pack the std::map-style state into flat arrays and call libvmm_ba.so (MI355X); nothing here computes
+residuals or solves on the CPU.
+
+Out of scope in this round (SURVEY.md section 8(f) "next" rows): startReconstruction's incremental
+driver (it needs the OpenCV PnP initialisation, src/TagReconstructor.cpp:156,167-230) -- callers
+provide initial poses through setReconstructedTags / setReconstructedCameras instead.
+"""
+import math
+
+import numpy as np
+
+from . import engine as _engine
+
+
+# ---- plain data types (DetectionResults.h:10-37, Camera.h:9-18, TagReconstructor.h:15-53) -----------
+
+
+class TagObservation:
+    def __init__(self, imageId=-1, tagId=-1, corners=None):
+        self.imageId = int(imageId)
+        self.tagId = int(tagId)
+        # observed tag corners LL, LR, UR, UL as (u, v)
+        self.corners = np.zeros((4, 2)) if corners is None else np.asarray(corners, np.float64).reshape(4, 2)
+
+
+class TagImg:
+    def __init__(self, imageId=-1, filename=""):
+        self.imageId = int(imageId)
+        self.filename = filename
+
+
+class Tag:
+    def __init__(self, tagId, tagType, width, height):
+        self.tagId = int(tagId)
+        self.tagType = tagType
+        self.width = float(width)
+        self.height = float(height)
+
+
+class DetectionResult:
+    def __init__(self, images=None, tags=None, tagObservations=None):
+        self.images = list(images or [])
+        self.tags = list(tags or [])
+        self.tagObservations = list(tagObservations or [])
+
+
+def _quat_to_R(q):
+    """Eigen::Quaterniond::toRotationMatrix for q = (w, x, y, z) (no normalisation)."""
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _quat_mul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                     a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+                     a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+class Camera:
+    """World->camera pose; q = (w, x, y, z), default identity (Camera.h:13-14)."""
+
+    def __init__(self, cameraId=-1, q=None, t=None):
+        self.cameraId = int(cameraId)
+        self.q = np.array([1.0, 0.0, 0.0, 0.0]) if q is None else np.asarray(q, np.float64).reshape(4).copy()
+        self.t = np.zeros(3) if t is None else np.asarray(t, np.float64).reshape(3).copy()
+
+    def quat(self):
+        return self.q.copy()
+
+    def setQuat(self, quat):
+        self.q = np.asarray(quat, np.float64).reshape(4).copy()
+
+
+class ReconstructedTag:
+    """Tag->world pose plus the tag's metric size (TagReconstructor.h:15-53)."""
+
+    def __init__(self, id=-1, tagType="", q=None, t=None, tagWidth=0.0, tagHeight=0.0):
+        self.id = int(id)
+        self.tagType = tagType
+        self.q = np.array([1.0, 0.0, 0.0, 0.0]) if q is None else np.asarray(q, np.float64).reshape(4).copy()
+        self.t = np.zeros(3) if t is None else np.asarray(t, np.float64).reshape(3).copy()
+        self.tagWidth = float(tagWidth)
+        self.tagHeight = float(tagHeight)
+
+    def quat(self):
+        return self.q.copy()
+
+    def setQuat(self, quat):
+        self.q = np.asarray(quat, np.float64).reshape(4).copy()
+
+    def computeLocalMarkerCorners3D(self):
+        w, h = self.tagWidth, self.tagHeight   # TagReconstructor.h:47-50: LL, LR, UR, UL
+        return [np.array([-w / 2.0, -h / 2.0, 0.0]), np.array([w / 2.0, -h / 2.0, 0.0]),
+                np.array([w / 2.0, h / 2.0, 0.0]), np.array([-w / 2.0, h / 2.0, 0.0])]
+
+    def computeMarkerCorners3D(self):
+        R = _quat_to_R(self.q)
+        return [R @ p + self.t for p in self.computeLocalMarkerCorners3D()]
+
+
+class CameraModel:
+    """OpenCV pinhole + 5-coefficient distortion (CameraModel.h:12-34)."""
+
+    def __init__(self, fx=0.0, fy=0.0, cx=0.0, cy=0.0, distortionCoefficients=None, verticalResolution=0,
+                 horizontalResolution=0):
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+        self.distortionCoefficients = (np.zeros(5) if distortionCoefficients is None
+                                       else np.asarray(distortionCoefficients, np.float64).reshape(5).copy())
+        self.verticalResolution = int(verticalResolution)
+        self.horizontalResolution = int(horizontalResolution)
+
+    def getK(self):
+        """CameraModel::getK, src/CameraModel.cpp:28-36."""
+        K = np.eye(3)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2] = self.fx, self.fy, self.cx, self.cy
+        return K
+
+    def projectPoint(self, point3D, device=0):
+        """CameraModel::projectPoint, src/CameraModel.cpp:6-26: camera-frame point(s) -> pixel(s).
+
+        Accepts one point (3,) or a batch (n, 3); evaluated by the device kernel.
+        """
+        pts = np.asarray(point3D, np.float64)
+        single = pts.ndim == 1
+        uv = _engine.project_points([self.fx, self.fy, self.cx, self.cy], self.distortionCoefficients,
+                                    pts.reshape(-1, 3), device=device)
+        return uv[0] if single else uv
+
+
+# ---- the class whose hot path this package replaces --------------------------------------------------
+
+
+class TagReconstructor:
+    """Mirror of visual_marker_mapping::TagReconstructor (TagReconstructor.h:58-146)."""
+
+    def __init__(self, detection_result, device=0):
+        self.originTagId = -1                                  # src/TagReconstructor.cpp:70
+        self.detectionResults_ = detection_result
+        self.reconstructedTags = {}                            # tag id -> ReconstructedTag
+        self.reconstructedCameras = {}                         # image id -> Camera
+        self.camModel = CameraModel()
+        self.device = int(device)
+        self.lastSummary = None                                # summary of the last doBundleAdjustment
+
+    # -- trivial accessors (src/TagReconstructor.cpp:75-84, 818-842) --
+    def getLowestTag(self):
+        tags = self.detectionResults_.tags
+        m = tags[0].tagId     # the reference dereferences tags[0] unguarded (:77)
+        for t in tags:
+            if t.tagId < m:
+                m = t.tagId
+        return m
+
+    def getReconstructedTags(self):
+        return dict(self.reconstructedTags)
+
+    def getReconstructedCameras(self):
+        return dict(self.reconstructedCameras)
+
+    def setReconstructedTags(self, tags):
+        """Not in the reference API: stands in for the PnP initialisation of startReconstruction."""
+        self.reconstructedTags = {int(k): v for k, v in dict(tags).items()}
+
+    def setReconstructedCameras(self, cams):
+        """Not in the reference API: stands in for the PnP initialisation of startReconstruction."""
+        self.reconstructedCameras = {int(k): v for k, v in dict(cams).items()}
+
+    def getCameraModel(self):
+        return self.camModel
+
+    def setCameraModel(self, cameraModel):
+        self.camModel = cameraModel
+
+    def setOriginTagId(self, originTagId):
+        self.originTagId = int(originTagId)
+
+    def startReconstruction(self, numThreads=1):
+        raise NotImplementedError(
+            "startReconstruction (src/TagReconstructor.cpp:86-278) is the incremental driver around the hot "
+            "path; it needs OpenCV's PnP for initial poses and is a SURVEY.md 8(f) 'next' row.  Provide "
+            "initial poses with setReconstructedTags/setReconstructedCameras and call doBundleAdjustment.")
+
+    def moveTagIntoOrigin(self, tagId):
+        """src/TagReconstructor.cpp:314-338 (applies the same map to tags AND cameras, as the reference does)."""
+        if tagId not in self.reconstructedTags:
+            raise RuntimeError("Tag with id %d is not reconstructed." % tagId)
+        print("Transforming tag with id %d into origin." % tagId)
+        q0 = self.reconstructedTags[tagId].quat()
+        qinv = np.array([q0[0], -q0[1], -q0[2], -q0[3]]) / float(q0 @ q0)
+        t0 = self.reconstructedTags[tagId].t.copy()
+        R = _quat_to_R(qinv)
+        for tag in self.reconstructedTags.values():
+            tag.setQuat(_quat_mul(qinv, tag.quat()))
+            tag.t = R @ (tag.t - t0)
+        for cam in self.reconstructedCameras.values():
+            cam.setQuat(_quat_mul(qinv, cam.quat()))
+            cam.t = R @ (cam.t - t0)
+        print("Finished transforming Tags")
+
+    # -- packing of the map state into the flat arrays of the C-ABI --
+    def _pack(self, for_ba):
+        """Dense problem arrays exactly as doBundleAdjustment assembles the ceres::Problem
+        (src/TagReconstructor.cpp:663-724): tags in map (id) order; cameras with >= 1 reconstructed tag
+        in map order (for_ba) or all cameras (statistics); observations whose camera and tag are both
+        reconstructed, in file order."""
+        tag_ids = sorted(self.reconstructedTags)
+        tag_index = {tid: k for k, tid in enumerate(tag_ids)}
+        tag_by_id = {t.tagId: t for t in self.detectionResults_.tags}
+        num_tags_in_image = {}
+        for ob in self.detectionResults_.tagObservations:
+            if ob.tagId in tag_index:
+                num_tags_in_image[ob.imageId] = num_tags_in_image.get(ob.imageId, 0) + 1   # :679-684
+        cam_ids = [cid for cid in sorted(self.reconstructedCameras)
+                   if (num_tags_in_image.get(cid, 0) > 0 or not for_ba)]                    # :689-690
+        cam_index = {cid: k for k, cid in enumerate(cam_ids)}
+        obs_cam, obs_tag, obs_px = [], [], []
+        for ob in self.detectionResults_.tagObservations:                                    # :699-708
+            if ob.imageId in cam_index and ob.tagId in tag_index:
+                obs_cam.append(cam_index[ob.imageId])
+                obs_tag.append(tag_index[ob.tagId])
+                obs_px.append(np.asarray(ob.corners, np.float64).reshape(8))
+        cam_qt = np.array([np.r_[self.reconstructedCameras[c].q, self.reconstructedCameras[c].t] for c in cam_ids],
+                          np.float64).reshape(-1, 7)
+        tag_qt = np.array([np.r_[self.reconstructedTags[t].q, self.reconstructedTags[t].t] for t in tag_ids],
+                          np.float64).reshape(-1, 7)
+        # the cost functor receives the DETECTION tag's width/height but builds the quad from the
+        # reconstructed tag's (:713 vs :718); only the quad enters the arithmetic
+        tag_wh = np.array([[self.reconstructedTags[t].tagWidth, self.reconstructedTags[t].tagHeight] for t in tag_ids],
+                          np.float64).reshape(-1, 2)
+        _ = tag_by_id
+        fixed = tag_index.get(self.originTagId, -1)                                          # :669-673
+        intr = [self.camModel.fx, self.camModel.fy, self.camModel.cx, self.camModel.cy]
+        return dict(tag_ids=tag_ids, cam_ids=cam_ids, intr=intr, dist=self.camModel.distortionCoefficients,
+                    cam_qt=cam_qt, tag_qt=tag_qt, tag_wh=tag_wh, fixed=fixed,
+                    obs_cam=np.asarray(obs_cam, np.int32), obs_tag=np.asarray(obs_tag, np.int32),
+                    obs_px=np.asarray(obs_px, np.float64).reshape(-1, 8))
+
+    def _engine_for(self, p, **kw):
+        return _engine.BundleAdjuster(p["intr"], p["dist"], p["cam_qt"], p["tag_qt"], p["tag_wh"], p["fixed"],
+                                      p["obs_cam"], p["obs_tag"], p["obs_px"], device=self.device, **kw)
+
+    # -- the hot path --
+    def doBundleAdjustment(self, maxNumIterations, ceresThreads=1, robustify=True, printSummary=False,
+                           elimination=_engine.ELIM_AUTO):
+        """src/TagReconstructor.cpp:646-743.  Poses are updated in place like the reference's map nodes."""
+        p = self._pack(for_ba=True)
+        if len(p["cam_ids"]) == 0 or len(p["tag_ids"]) == 0 or len(p["obs_cam"]) == 0:
+            # Ceres solves an empty problem trivially: CONVERGENCE, nothing changes
+            print("Solution %d" % _engine.CONVERGENCE)
+            self.lastSummary = {"termination_type": _engine.CONVERGENCE, "iterations": 1}
+            return
+        ba = self._engine_for(p, elimination=elimination)
+        try:
+            opts = _engine.default_options(max_num_iterations=int(maxNumIterations), robustify=int(bool(robustify)),
+                                           num_threads=int(ceresThreads))
+            summary = ba.solve(opts, trace_capacity=int(maxNumIterations) + 2 if printSummary else 0)
+            cam, tag = ba.get_state()
+        finally:
+            ba.close()
+        for k, cid in enumerate(p["cam_ids"]):
+            self.reconstructedCameras[cid].q = cam[k, :4].copy()
+            self.reconstructedCameras[cid].t = cam[k, 4:].copy()
+        for k, tid in enumerate(p["tag_ids"]):
+            self.reconstructedTags[tid].q = tag[k, :4].copy()
+            self.reconstructedTags[tid].t = tag[k, 4:].copy()
+        self.lastSummary = summary
+        print("Solution %d" % summary["termination_type"])                                   # :740
+        if printSummary:                                                                     # :741-742
+            print("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius")
+            for it in summary["trace"]:
+                print("%4d  %.6e  %9.2e  %9.2e  %9.2e  %9.2e  %9.2e" % (
+                    it["iteration"], it["cost"], it["cost_change"], it["gradient_max_norm"], it["step_norm"],
+                    it["relative_decrease"], it["trust_region_radius"]))
+            print("Cost: initial %.6e final %.6e; iterations %d; time in solver %.4f s" % (
+                summary["initial_cost"], summary["final_cost"], summary["iterations"], summary["time_solve_s"]))
+            # the covariance report of :744-783 (stdout only) is a SURVEY.md 8(f) 'next' row
+
+    # -- reprojection statistics + pruning (src/TagReconstructor.cpp:340-455, 786-816) --
+    def _stats(self, per_corner):
+        p = self._pack(for_ba=False)
+        if len(p["cam_ids"]) == 0 or len(p["tag_ids"]) == 0:
+            return p, np.zeros(0), np.zeros(0), 0.0, np.zeros((0, 8))
+        ba = self._engine_for(p)
+        try:
+            pc, pt, avg, corner = ba.reprojection_stats(per_corner=per_corner)
+        finally:
+            ba.close()
+        return p, pc, pt, avg, corner
+
+    def computeReprojectionErrorPerImg(self):
+        """:340-385 -- image id -> mean corner reprojection error; -1.0 for a camera without observations."""
+        p, pc, _, _, _ = self._stats(False)
+        return {cid: float(pc[k]) for k, cid in enumerate(p["cam_ids"])}
+
+    def computeReprojectionErrorPerTag(self):
+        """:387-428 -- returns (tag id -> mean error, avg).  The reference returns avg through a reference
+        parameter; tags without observations do not appear in the map."""
+        p, _, pt, avg, _ = self._stats(False)
+        return {tid: float(pt[k]) for k, tid in enumerate(p["tag_ids"]) if not math.isnan(pt[k])}, float(avg)
+
+    def computeReprojectionErrorPerCorner(self):
+        """:430-455 -- list of signed (du, dv) per detected corner, observation order."""
+        _, _, _, _, corner = self._stats(True)
+        return [corner.reshape(-1, 2)[i].copy() for i in range(corner.size // 2)]
+
+    def removeBadMarkers(self, threshold):
+        """:786-802."""
+        reperrors, _avg = self.computeReprojectionErrorPerTag()
+        for tid in sorted(reperrors):
+            if reperrors[tid] > threshold and tid != self.originTagId:
+                print("Removing bad marker with id %d and reprojection error %g" % (tid, reperrors[tid]))
+                del self.reconstructedTags[tid]
+
+    def removeBadCameras(self, threshold):
+        """:804-816."""
+        rep = self.computeReprojectionErrorPerImg()
+        for cid in sorted(rep):
+            if rep[cid] > threshold or rep[cid] < 0:
+                print("Removing bad camera with id %d and reprojection error %g" % (cid, rep[cid]))
+                del self.reconstructedCameras[cid]
+
+
+def detection_result_from_arrays(obs_cam, obs_tag, obs_px, tag_wh, n_cams, tag_type="apriltag_36h11"):
+    """Builds a DetectionResult (DetectionResults.h:32-37) from flat arrays; image id = camera index."""
+    images = [TagImg(i, "img_%05d.jpg" % i) for i in range(n_cams)]
+    tags = [Tag(t, tag_type, tag_wh[t][0], tag_wh[t][1]) for t in range(len(tag_wh))]
+    obs = [TagObservation(int(c), int(t), np.asarray(px, np.float64).reshape(4, 2))
+           for c, t, px in zip(obs_cam, obs_tag, obs_px)]
+    return DetectionResult(images, tags, obs)
