@@ -163,13 +163,28 @@ def main():
             scale = 1e-9 if v["unit"] == "GB/s" else 1e-12
             v["achieved"] = v["alg"] * scale / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
             v["frac"] = v["achieved"] / v["peak"]
+        # HBM bytes per launch from the PMC passes committed under profiles/ (tools/gpu_pmc.sh +
+        # tools/pmc_to_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction)
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if a.config == 2 and a.visibility == 1.0 and os.path.exists(tpath):
+            with open(tpath) as f:
+                bpl = json.load(f)["bytes_per_launch"]
+            nb = (n_red + 63) // 64
+            traffic = {"eval_jacobian": bpl.get("eval_jacobian"), "eval_cost": bpl.get("eval_cost"),
+                       "schur_syrk": bpl.get("schur_syrk"),
+                       "cholesky_solve": nb * bpl.get("chol_panel", 0) + (nb - 1) * bpl.get("chol_update", 0)
+                       + nb * bpl.get("backsolve_step", 0)}
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
-        line["roofline"] = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                            "unit": d["unit"], "frac": d["frac"], "traffic": None,
+        names = {"cholesky_solve": "cholesky_solve = k_chol_panel + k_chol_update + k_backsolve_step (%d launches)"
+                                   % (3 * ((n_red + 63) // 64) - 1)}
+        line["roofline"] = {"kernel": names.get(dom, dom), "bound": d["bound"], "achieved": d["achieved"],
+                            "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": traffic.get(dom),
                             "avg_launch_ms": d["ms"]}
         line["kernels"] = {k: {"ms": v["ms"], "bound": v["bound"], "achieved": v["achieved"],
-                               "unit": v["unit"], "frac": v["frac"]} for k, v in kern.items()}
+                               "unit": v["unit"], "frac": v["frac"], "traffic": traffic.get(k)}
+                           for k, v in kern.items()}
         line["kernels"]["form_z"] = {"ms": kt["form_z_ms"]}
         line["kernels"]["backsub"] = {"ms": kt["backsub_ms"]}
         line["kernels"]["lm_iteration_enqueued"] = {"ms": kt["lm_iteration_ms"]}

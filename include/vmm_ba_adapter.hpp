@@ -1,0 +1,195 @@
+// vmm_ba_adapter.hpp -- header-only C++ adapter between visual_marker_mapping's own types and the
+// C-ABI of libvmm_ba.so (include/vmm_ba.h).
+//
+// It lets the reference keep its headers and class unchanged: the three hot-path member functions of
+// TagReconstructor (src/TagReconstructor.cpp:340-455, 646-743) and CameraModel::projectPoint
+// (src/CameraModel.cpp:6-26) become one-line calls into the function templates below
+// (INTEGRATION.md shows the patch).  The templates only assume what the reference's types offer:
+//   pose types     .q(i) i=0..3 (w,x,y,z), .t(i) i=0..2            Camera.h:13-14, TagReconstructor.h:19-20
+//   tags           .id, .tagWidth, .tagHeight                      TagReconstructor.h:17,21-22
+//   camera model   .fx .fy .cx .cy, .distortionCoefficients(i, 0)  CameraModel.h:14-19
+//   detections     .tagObservations[k].imageId/.tagId/.corners[c].x()/.y()   DetectionResults.h:10-18
+// so they work with Eigen types when Eigen is present and with any look-alike otherwise
+// (tests/cpp/adapter_test.cpp uses 30-line POD stand-ins, this image has no Eigen).
+#ifndef VMM_BA_ADAPTER_HPP_
+#define VMM_BA_ADAPTER_HPP_
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "vmm_ba.h"
+
+namespace vmm_ba_adapter {
+
+struct Packed {
+    std::vector<int> tag_ids, cam_ids;
+    std::vector<double> cam_qt, tag_qt, tag_wh, obs_px;
+    std::vector<int32_t> obs_cam, obs_tag;
+    vmm_ba_problem problem;
+};
+
+inline void check(int status, const char* what)
+{
+    if (status != VMM_BA_OK)
+        throw std::runtime_error(std::string(what) + ": " + vmm_ba_last_error());
+}
+
+// The problem doBundleAdjustment assembles (src/TagReconstructor.cpp:663-724): tags in map order,
+// cameras with >= 1 reconstructed tag (for_ba) or all reconstructed cameras (statistics),
+// observations whose camera and tag are both reconstructed, in file order.
+template <class TagMap, class CamMap, class Detection, class CamModel>
+Packed pack(const TagMap& tags, const CamMap& cams, const Detection& det, const CamModel& cm, int originTagId,
+            bool for_ba)
+{
+    Packed p;
+    std::map<int, int> tag_index, cam_index, tags_in_image;
+    for (const auto& kv : tags) {
+        tag_index[kv.first] = (int)p.tag_ids.size();
+        p.tag_ids.push_back(kv.first);
+        for (int i = 0; i < 4; ++i) p.tag_qt.push_back(kv.second.q(i));
+        for (int i = 0; i < 3; ++i) p.tag_qt.push_back(kv.second.t(i));
+        p.tag_wh.push_back(kv.second.tagWidth);
+        p.tag_wh.push_back(kv.second.tagHeight);
+    }
+    for (const auto& ob : det.tagObservations)
+        if (tag_index.count(ob.tagId))
+            tags_in_image[ob.imageId]++;                              // :679-684
+    for (const auto& kv : cams) {
+        if (for_ba && !tags_in_image[kv.first])                       // :689-690
+            continue;
+        cam_index[kv.first] = (int)p.cam_ids.size();
+        p.cam_ids.push_back(kv.first);
+        for (int i = 0; i < 4; ++i) p.cam_qt.push_back(kv.second.q(i));
+        for (int i = 0; i < 3; ++i) p.cam_qt.push_back(kv.second.t(i));
+    }
+    for (const auto& ob : det.tagObservations) {                      // :699-708
+        const auto c = cam_index.find(ob.imageId);
+        const auto t = tag_index.find(ob.tagId);
+        if (c == cam_index.end() || t == tag_index.end())
+            continue;
+        p.obs_cam.push_back(c->second);
+        p.obs_tag.push_back(t->second);
+        for (int k = 0; k < 4; ++k) {
+            p.obs_px.push_back(ob.corners[k].x());
+            p.obs_px.push_back(ob.corners[k].y());
+        }
+    }
+    vmm_ba_problem& q = p.problem;
+    q.intr[0] = cm.fx; q.intr[1] = cm.fy; q.intr[2] = cm.cx; q.intr[3] = cm.cy;
+    for (int i = 0; i < 5; ++i) q.dist[i] = cm.distortionCoefficients(i, 0);
+    q.n_cams = (int32_t)p.cam_ids.size();
+    q.n_tags = (int32_t)p.tag_ids.size();
+    q.cam_qt = p.cam_qt.data();
+    q.tag_qt = p.tag_qt.data();
+    q.tag_wh = p.tag_wh.data();
+    const auto o = tag_index.find(originTagId);                       // :669-673
+    q.fixed_tag = (o == tag_index.end()) ? -1 : o->second;
+    q.n_obs = (int64_t)p.obs_cam.size();
+    q.obs_cam = p.obs_cam.data();
+    q.obs_tag = p.obs_tag.data();
+    q.obs_px = p.obs_px.data();
+    return p;
+}
+
+// Body of TagReconstructor::doBundleAdjustment (src/TagReconstructor.cpp:646-743).  Updates the map
+// nodes in place, prints "Solution <termination_type>" like :740.  Returns the termination type.
+template <class TagMap, class CamMap, class Detection, class CamModel>
+int doBundleAdjustment(TagMap& tags, CamMap& cams, const Detection& det, const CamModel& cm, int originTagId,
+                       int maxNumIterations, size_t ceresThreads, bool robustify = true, bool printSummary = false,
+                       int device = 0)
+{
+    Packed p = pack(tags, cams, det, cm, originTagId, true);
+    if (p.problem.n_cams == 0 || p.problem.n_tags == 0 || p.problem.n_obs == 0) {
+        std::cout << "Solution " << VMM_BA_CONVERGENCE << std::endl;
+        return VMM_BA_CONVERGENCE;
+    }
+    vmm_ba_create_options co;
+    vmm_ba_default_create_options(&co);
+    co.device = device;
+    vmm_ba_handle h = nullptr;
+    check(vmm_ba_create(&p.problem, &co, &h), "vmm_ba_create");
+    vmm_ba_options o;
+    vmm_ba_default_options(&o);
+    o.max_num_iterations = maxNumIterations;
+    o.num_threads = (int32_t)ceresThreads;
+    o.robustify = robustify ? 1 : 0;
+    vmm_ba_summary s;
+    s.trace = nullptr;
+    s.trace_capacity = 0;
+    int rc = vmm_ba_solve(h, &o, &s);
+    if (rc == VMM_BA_OK)
+        rc = vmm_ba_get_state(h, p.cam_qt.data(), p.tag_qt.data());
+    vmm_ba_destroy(h);
+    check(rc, "vmm_ba_solve");
+    for (size_t k = 0; k < p.cam_ids.size(); ++k) {
+        auto& c = cams.at(p.cam_ids[k]);
+        for (int i = 0; i < 4; ++i) c.q(i) = p.cam_qt[7 * k + i];
+        for (int i = 0; i < 3; ++i) c.t(i) = p.cam_qt[7 * k + 4 + i];
+    }
+    for (size_t k = 0; k < p.tag_ids.size(); ++k) {
+        auto& t = tags.at(p.tag_ids[k]);
+        for (int i = 0; i < 4; ++i) t.q(i) = p.tag_qt[7 * k + i];
+        for (int i = 0; i < 3; ++i) t.t(i) = p.tag_qt[7 * k + 4 + i];
+    }
+    std::cout << "Solution " << s.termination_type << std::endl;     // :740
+    if (printSummary)                                                 // :741-742 (FullReport stand-in)
+        std::cout << "vmm_ba: iterations " << s.iterations << ", initial cost " << s.initial_cost
+                  << ", final cost " << s.final_cost << ", solver time " << s.time_solve_s << " s" << std::endl;
+    return s.termination_type;
+}
+
+struct Stats {
+    std::map<int, double> per_img, per_tag;
+    double avg = 0.0;
+    std::vector<std::array<double, 2>> per_corner;
+};
+
+// Bodies of computeReprojectionErrorPerImg / PerTag / PerCorner (src/TagReconstructor.cpp:340-455).
+template <class TagMap, class CamMap, class Detection, class CamModel>
+Stats reprojectionStatistics(const TagMap& tags, const CamMap& cams, const Detection& det, const CamModel& cm,
+                             bool want_corners, int device = 0)
+{
+    Stats out;
+    Packed p = pack(tags, cams, det, cm, -1, false);
+    if (p.problem.n_cams == 0 || p.problem.n_tags == 0)
+        return out;
+    vmm_ba_create_options co;
+    vmm_ba_default_create_options(&co);
+    co.device = device;
+    vmm_ba_handle h = nullptr;
+    check(vmm_ba_create(&p.problem, &co, &h), "vmm_ba_create");
+    std::vector<double> pc(p.cam_ids.size()), pt(p.tag_ids.size()), corner(want_corners ? p.obs_px.size() : 0);
+    const int rc = vmm_ba_reprojection_stats(h, pc.data(), pt.data(), &out.avg, want_corners ? corner.data() : nullptr);
+    vmm_ba_destroy(h);
+    check(rc, "vmm_ba_reprojection_stats");
+    for (size_t k = 0; k < p.cam_ids.size(); ++k)
+        out.per_img[p.cam_ids[k]] = pc[k];                            // -1.0 for cameras without observations
+    for (size_t k = 0; k < p.tag_ids.size(); ++k)
+        if (!std::isnan(pt[k]))
+            out.per_tag[p.tag_ids[k]] = pt[k];
+    for (size_t i = 0; i + 1 < corner.size(); i += 2)
+        out.per_corner.push_back({ corner[i], corner[i + 1] });
+    return out;
+}
+
+// Body of CameraModel::projectPoint (src/CameraModel.cpp:6-26) for one camera-frame point.
+template <class CamModel>
+std::array<double, 2> projectPoint(const CamModel& cm, double X, double Y, double Z, int device = 0)
+{
+    const double intr[4] = { cm.fx, cm.fy, cm.cx, cm.cy };
+    double dist[5];
+    for (int i = 0; i < 5; ++i) dist[i] = cm.distortionCoefficients(i, 0);
+    const double pc[3] = { X, Y, Z };
+    double uv[2];
+    check(vmm_ba_project_points(intr, dist, 1, pc, uv, device), "vmm_ba_project_points");
+    return { uv[0], uv[1] };
+}
+
+} // namespace vmm_ba_adapter
+#endif

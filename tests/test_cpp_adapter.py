@@ -1,0 +1,72 @@
+"""The header-only C++ adapter (include/vmm_ba_adapter.hpp) driven through tests/cpp/adapter_test,
+a C++11 program whose POD types spell their members like the reference's Eigen-based ones."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "adapter_test")
+
+
+def _scene_text(s, tag_ids, cam_ids):
+    lines = [" ".join(repr(float(v)) for v in s.intr), " ".join(repr(float(v)) for v in s.dist),
+             "%d %d %d %d" % (len(cam_ids), len(tag_ids), s.n_obs, tag_ids[0])]
+    for k, cid in enumerate(cam_ids):
+        lines.append("%d " % cid + " ".join(repr(float(v)) for v in s.cam_init[k]))
+    for k, tid in enumerate(tag_ids):
+        lines.append("%d " % tid + " ".join(repr(float(v)) for v in s.tag_init[k]) + " %r %r" % (float(s.tag_wh[k][0]), float(s.tag_wh[k][1])))
+    for c, t, px in zip(s.obs_cam, s.obs_tag, s.obs_px):
+        lines.append("%d %d " % (cam_ids[c], tag_ids[t]) + " ".join(repr(float(v)) for v in px))
+    return "\n".join(lines) + "\n"
+
+
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
+
+
+def test_adapter_compiles_as_cxx11_and_fails_loudly_without_gpu():
+    _build()
+    assert os.path.exists(EXE)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present: covered by the gpu test")
+    except ImportError:
+        pass
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=3, n_tags=2)
+    r = subprocess.run([EXE], input=_scene_text(s, [5, 9], [1, 2, 3]), capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr     # std::runtime_error caught in main
+
+
+@pytest.mark.gpu
+def test_adapter_matches_python_engine():
+    _build()
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1)
+    tag_ids = [100 + 2 * k for k in range(len(s.tag_init))]
+    cam_ids = [7 + 3 * k for k in range(len(s.cam_init))]
+    r = subprocess.run([EXE], input=_scene_text(s, tag_ids, cam_ids), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Solution 0" in r.stdout
+    cams, tags, avg = {}, {}, None
+    for line in r.stdout.splitlines():
+        f = line.split()
+        if f[0] == "CAM":
+            cams[int(f[1])] = np.array(f[2:], float)
+        elif f[0] == "TAG":
+            tags[int(f[1])] = np.array(f[2:], float)
+        elif f[0] == "AVG":
+            avg, ncorner, uv = float(f[1]), int(f[3]), np.array(f[5:7], float)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px)
+    ba.solve(eng.default_options(robustify=1))
+    cam, tag = ba.get_state()
+    _, _, ref_avg, _ = ba.reprojection_stats()
+    ba.close()
+    np.testing.assert_array_equal(np.array([cams[c] for c in cam_ids]), cam)   # same library, same bits
+    np.testing.assert_array_equal(np.array([tags[t] for t in tag_ids]), tag)
+    assert avg == ref_avg and ncorner == 4 * s.n_obs
+    np.testing.assert_allclose(uv, eng.project_points(s.intr, s.dist, [[0.3, -0.2, 2.5]])[0], rtol=0, atol=0)

@@ -193,15 +193,18 @@ __global__ __launch_bounds__(256) void k_syrk(const LmCtl* ctl, const double* __
     const int I0 = bi * kNB, J0 = bj * kNB;
     const bool diag = (bi == bj);
 
-    __shared__ double As[kKT * kLdsRow];
-    __shared__ double Bs[kKT * kLdsRow];
+    // K tiles of 32 rows, double-buffered in LDS; the next tile's global loads are issued before the
+    // current tile's 32 MFMAs per wave so that the memory latency hides behind the wave's own compute.
+    constexpr int KT = 32;
+    __shared__ __attribute__((aligned(16))) double As[2][KT * kLdsRow];
+    __shared__ __attribute__((aligned(16))) double Bs[2][KT * kLdsRow];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    // global->LDS: 16 rows x 64 cols = 1024 doubles per operand, 256 threads x 4 doubles
-    const int lr = tid >> 4;          // 0..15 row within the K tile
-    const int lc = (tid & 15) * 4;    // 0..60 column
+    // global->LDS: 32 rows x 64 cols = 2048 doubles per operand, 256 threads x 2 x double4
+    const int lr = tid >> 4;          // 0..15 (+16 for the second half)
+    const int lc = (tid & 15) * 4;    // 0..60
     double4_t acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -210,23 +213,38 @@ __global__ __launch_bounds__(256) void k_syrk(const LmCtl* ctl, const double* __
             acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
 
     const int fk = lane >> 4, fi = lane & 15;
-    for (int kk = 0; kk < k_chunk; kk += kKT) {
-        const double* zr = Z + (int64_t)(k0 + kk + lr) * ldz;
-        const double4_t va = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
-        double4_t vb = va;
-        if (!diag)
-            vb = *reinterpret_cast<const double4_t*>(zr + J0 + lc);
-        __syncthreads();  // previous tile fully consumed
-        *reinterpret_cast<double4_t*>(&As[lr * kLdsRow + lc]) = va;
-        if (!diag)
-            *reinterpret_cast<double4_t*>(&Bs[lr * kLdsRow + lc]) = vb;
-        __syncthreads();
-        const double* Bp = diag ? As : Bs;
+    const int n_kt = k_chunk / KT;      // host guarantees k_chunk % 32 == 0
+    double4_t va[2], vb[2];
+    auto gload = [&](int kt) {
 #pragma unroll
-        for (int ks = 0; ks < kKT / 4; ++ks) {
+        for (int h = 0; h < 2; ++h) {
+            const double* zr = Z + (int64_t)(k0 + kt * KT + lr + 16 * h) * ldz;
+            va[h] = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
+            vb[h] = diag ? va[h] : *reinterpret_cast<const double4_t*>(zr + J0 + lc);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<double4_t*>(&As[buf][(lr + 16 * h) * kLdsRow + lc]) = va[h];
+            if (!diag)
+                *reinterpret_cast<double4_t*>(&Bs[buf][(lr + 16 * h) * kLdsRow + lc]) = vb[h];
+        }
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < n_kt)
+            gload(kt + 1);
+        const double* Ap = As[buf];
+        const double* Bp = diag ? As[buf] : Bs[buf];
+#pragma unroll
+        for (int ks = 0; ks < KT / 4; ++ks) {
             const int row = (ks * 4 + fk) * kLdsRow;
-            const double a0 = As[row + wi * 32 + fi];
-            const double a1 = As[row + wi * 32 + 16 + fi];
+            const double a0 = Ap[row + wi * 32 + fi];
+            const double a1 = Ap[row + wi * 32 + 16 + fi];
             const double b0 = Bp[row + wj * 32 + fi];
             const double b1 = Bp[row + wj * 32 + 16 + fi];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
@@ -234,6 +252,9 @@ __global__ __launch_bounds__(256) void k_syrk(const LmCtl* ctl, const double* __
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (kt + 1 < n_kt)
+            lstore(buf ^ 1);
+        __syncthreads();
     }
     double* Cb = C + (MODE == SYRK_SLAB ? (size_t)blockIdx.y * slab_stride : 0);
 #pragma unroll
