@@ -109,6 +109,8 @@ struct Engine {
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
     double* P = nullptr;            // [kNB][ldz] transposed Cholesky panel
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
+    unsigned* flags = nullptr;      // [256] hand-off flags of the chained back-substitution + [1] epoch word
+    bool no_chain = false;          // VMM_BA_NO_CHAIN=1: per-block back-substitution kernels
     double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)
     double* step_comm = nullptr;    // [6*n_e + 2]: delta of the eliminated family | cross term
     double* cost_comm = nullptr;    // [2] candidate cost (all-reduced)

@@ -404,6 +404,114 @@ __global__ __launch_bounds__(256) void k_backsolve_step(const LmCtl* ctl, double
         y[kb * kNB + c] = yj;
 }
 
+// Whole back-substitution L^T y = w in ONE launch: workgroup p owns block m = n_blk-1-p and depends on
+// the workgroups before it (dispatched earlier), which publish their 64 unknowns through agent-scope
+// (sc1) stores followed by a flag (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "valid
+// forms": one lane of the storing wave signals after that wave's s_waitcnt vmcnt(0); the consumer polls
+// with sc1 loads from one lane, joins a workgroup barrier, then reads the payload with sc1 loads).
+// While it waits, a workgroup already holds the next L tile in registers, so each hand-off costs the
+// flag latency + a 64x64 GEMV slice; the 19 kernel boundaries of the per-block version disappear.
+// Every spin is bounded: on a timeout the solve is flagged as failed (treated like a failed Cholesky
+// by the LM loop) and the flag is still published so that no other workgroup is left waiting.
+constexpr unsigned kSpinLimit = 1u << 22;
+
+__global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const double* __restrict__ S, int ld,
+                                                         int n_pad, int n_blk, double* y,
+                                                         const double* __restrict__ dinv, unsigned* flags,
+                                                         unsigned* epoch_word)
+{
+    if (ctl->done || ctl->lin_fail)
+        return;
+    __shared__ double L[64 * kLd];
+    __shared__ double red[4][64];
+    __shared__ double ws[64];
+    __shared__ double di[64];
+    __shared__ int s_timeout;
+    const int m = n_blk - 1 - (int)blockIdx.x;
+    const int tid = threadIdx.x;
+    const int c = tid & 63, part = tid >> 6;
+    const unsigned epoch = *epoch_word + 1u;   // every workgroup reads it before workgroup n_blk-1 (the last) bumps it
+    const int K0 = m * kNB;
+    if (tid == 0)
+        s_timeout = 0;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, cc = idx & 63;
+        L[r * kLd + cc] = (cc <= r) ? S[(int64_t)(K0 + r) * ld + K0 + cc] : 0.0;
+    }
+    if (tid < 64)
+        di[tid] = dinv[K0 + tid];
+    double acc = 0.0;
+    double lt[16], ln[16];
+    int j = n_blk - 1;
+    if (j > m) {
+        const double* Lb = S + (int64_t)(j * kNB + part * 16) * ld + K0 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            lt[r] = Lb[(int64_t)r * ld];
+    }
+    for (; j > m; --j) {
+        if (j - 1 > m) {   // next tile requested before the wait
+            const double* Lb = S + (int64_t)((j - 1) * kNB + part * 16) * ld + K0 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ln[r] = Lb[(int64_t)r * ld];
+        }
+        if (tid == 0) {
+            unsigned n = 0;
+            while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++n > kSpinLimit) {
+                    s_timeout = 1;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        const double* yj = y + j * kNB + part * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc += lt[r] * __hip_atomic_load(&yj[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            lt[r] = ln[r];
+    }
+    red[part][c] = acc;
+    __syncthreads();
+    double wc = 0.0;
+    if (part == 0)
+        wc = S[(int64_t)n_pad * ld + K0 + c] - ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    double yv = 0.0;
+    for (int j0 = 60; j0 >= 0; j0 -= 4) {
+        if (part == 0)
+            ws[c] = wc;
+        __syncthreads();
+        if (part == 0) {
+            const double* D = L + j0 * kLd + j0;
+            const double v3 = ws[j0 + 3] * di[j0 + 3];
+            const double v2 = (ws[j0 + 2] - D[3 * kLd + 2] * v3) * di[j0 + 2];
+            const double v1 = (ws[j0 + 1] - D[2 * kLd + 1] * v2 - D[3 * kLd + 1] * v3) * di[j0 + 1];
+            const double v0 = (ws[j0] - D[kLd] * v1 - D[2 * kLd] * v2 - D[3 * kLd] * v3) * di[j0];
+            if (c >= j0 && c < j0 + 4)
+                yv = (c == j0) ? v0 : (c == j0 + 1 ? v1 : (c == j0 + 2 ? v2 : v3));
+            if (c < j0)
+                wc -= L[j0 * kLd + c] * v0 + L[(j0 + 1) * kLd + c] * v1 + L[(j0 + 2) * kLd + c] * v2
+                    + L[(j0 + 3) * kLd + c] * v3;
+        }
+        __syncthreads();
+    }
+    if (part == 0) {
+        __hip_atomic_store(&y[K0 + c], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            if (s_timeout)
+                ctl->lin_fail = 1;
+            __hip_atomic_store(&flags[m], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (m == 0)
+                *epoch_word = epoch;   // all other workgroups have published, hence read the old value
+        }
+    }
+}
+
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl)
 {
     const int n_blk = n_pad / kNB;
@@ -419,8 +527,15 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
             hipLaunchKernelGGL(k_chol_update, dim3(tiles), dim3(256), 0, e.stream, ctl, S, ld, n_blk, k, e.P);
         }
     }
-    for (int kb = n_blk - 1; kb >= 0; --kb)
-        hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y, e.dinv);
+    // one chained launch while every workgroup of the chain can be resident; the per-block kernels otherwise
+    if (n_blk <= 200 && e.flags && !e.no_chain) {
+        hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
+                           e.flags, e.flags + 256);
+    } else {
+        for (int kb = n_blk - 1; kb >= 0; --kb)
+            hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y,
+                               e.dinv);
+    }
 }
 
 } // namespace vmm

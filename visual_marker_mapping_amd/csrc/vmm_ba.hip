@@ -329,6 +329,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     {
         const char* ng = getenv("VMM_BA_NO_GRAPH");
         e.use_graph = !(ng && ng[0] == '1');
+        const char* nc = getenv("VMM_BA_NO_CHAIN");
+        e.no_chain = nc && nc[0] == '1';
     }
     e.K.fx = p->intr[0]; e.K.fy = p->intr[1]; e.K.cx = p->intr[2]; e.K.cy = p->intr[3];
     e.K.k1 = p->dist[0]; e.K.k2 = p->dist[1]; e.K.p1 = p->dist[2]; e.K.p2 = p->dist[3]; e.K.k3 = p->dist[4];
@@ -416,6 +418,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.P, (size_t)kNB * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.flags, 260))) return fail(rc);
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.step_comm, (size_t)6 * e.n_e + 2))) return fail(rc);
     if ((rc = dev_alloc(e, &e.cost_comm, 2))) return fail(rc);
@@ -721,6 +724,8 @@ static int make_scratch(Engine& e, int device, int ld)
     int rc;
     if ((rc = dev_alloc(e, &e.P, (size_t)kNB * ld))) return rc;
     if ((rc = dev_alloc(e, &e.dinv, (size_t)ld + kNB))) return rc;
+    if ((rc = dev_alloc(e, &e.flags, 260))) return rc;
+    { const char* nc = getenv("VMM_BA_NO_CHAIN"); e.no_chain = nc && nc[0] == '1'; }
     if ((rc = dev_alloc(e, &e.ctl, 1))) return rc;
     return VMM_BA_OK;
 }
