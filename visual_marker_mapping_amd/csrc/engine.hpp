@@ -115,7 +115,9 @@ struct Engine {
     double* step_comm = nullptr;    // [6*n_e + 2]: delta of the eliminated family | cross term
     double* cost_comm = nullptr;    // [2] candidate cost (all-reduced)
     double* part_cost = nullptr;    // [ordE.n_tasks]
-    double* part_cross = nullptr;   // [ordE.n_tasks]
+    double* part_cross = nullptr;   // [ordE.n_tasks] cross-term wave partials
+    double* part_k1 = nullptr;      // [ordE.n_tasks] candidate-cost wave partials
+    double* pose_part = nullptr;    // [n_pose][5] per-pose terms of the step decision
 
     LmCtl* ctl = nullptr;           // device
     LmCtl* ctl_host = nullptr;      // pinned
@@ -157,8 +159,7 @@ void launch_reduce_slabs(hipStream_t st, const LmCtl* ctl, const double* slabs, 
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl);
 // kernels_lm.hip
 void launch_zero_unless_eval(Engine& e, double* buf, size_t n);
-void launch_post_eval(Engine& e, const double* src);
-void launch_lm_begin(Engine& e);
+void launch_iter_begin(Engine& e, const double* src);
 void launch_backsub(Engine& e);
 void launch_candidate(Engine& e);
 void launch_decide(Engine& e);

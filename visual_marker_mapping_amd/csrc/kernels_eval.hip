@@ -407,7 +407,8 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
                        e.n_e, e.ordE.pose_task, e.ordE.part, H_E, g_E, e.part_cost /* per-pose cost */);
     hipLaunchKernelGGL(k_reduce_pose, dim3((e.n_f * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
                        e.n_f, e.ordF.pose_task, e.ordF.part, H_F, g_F, (double*)nullptr);
-    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1, e.ev_cost);
+    if (e.world > 1 || !use_ctl)   // single-GPU solves sum the pose costs in k_iter_begin
+        hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1, e.ev_cost);
 }
 
 void launch_sum(Engine& e, bool guard, const double* in, int n, double* out)
@@ -429,7 +430,7 @@ void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool gu
     a.tag_wh = e.tag_wh;
     a.robustify = robustify;
     a.huber_a = huber_a;
-    a.part = e.part_cross;  // scratch distinct from the pose-cost buffer
+    a.part = e.part_k1;
     a.ctl = guard ? e.ctl : nullptr;
     if (a.n_tasks <= 0)
         return;
@@ -443,7 +444,7 @@ void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, in
                  double* out_scalar)
 {
     launch_cost_kernel(e, cam, tag, guard, robustify, huber_a);
-    launch_sum(e, guard, e.part_cross, e.ordE.n_tasks, out_scalar);
+    launch_sum(e, guard, e.part_k1, e.ordE.n_tasks, out_scalar);
 }
 
 void launch_stats(Engine& e, double* part_cam, double* part_tag, double* per_corner_dev)

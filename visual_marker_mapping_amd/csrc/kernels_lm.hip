@@ -54,148 +54,168 @@ __device__ __forceinline__ double* pose_ptr(const PoseViews& v, int p, bool cand
     return (cand ? v.tag_cand : v.tag_qt) + 7 * (int64_t)(p - v.n_cams);
 }
 
-// After an evaluation at x: cost, Jacobi scaling (first evaluation only), gradient max-norm.
-// TrustRegionMinimizer::IterationZero / EvaluateGradientAndJacobian.
-__global__ __launch_bounds__(256) void k_post_eval(LmCtl* ctl, PoseViews pv, const double* __restrict__ src,
-                                                   double* __restrict__ dst, size_t small_count,
-                                                   const double* __restrict__ H, const double* __restrict__ g,
-                                                   const double* __restrict__ cost_slot,
-                                                   double* __restrict__ scale, int32_t* __restrict__ active)
-{
-    if (ctl->done || !ctl->need_jacobian)
-        return;
-    __shared__ double sh[256];
-    const int tid = threadIdx.x;
-    const int n_pose = pv.n_cams + pv.n_tags;
-    // multi-GPU: the all-reduced staging buffer becomes the working copy
-    if (src != dst) {
-        for (size_t i = tid; i < small_count; i += 256)
-            dst[i] = src[i];
-        __syncthreads();
-    }
-    const bool first = ctl->first_eval != 0;
-    const bool jacobi = ctl->jacobi_scaling != 0;
-    double xn = 0.0, gm = 0.0;
-    for (int p = tid; p < n_pose; p += 256) {
-        const double* Hp = H + 36 * (int64_t)p;
-        if (first) {
-            // blocks with zero Jacobian columns (constant origin tag, poses without observations)
-            // are not part of Ceres' reduced program
-            active[p] = (Hp[0] + Hp[7] + Hp[14]) > 0.0 ? 1 : 0;
-            for (int k = 0; k < 6; ++k)
-                scale[6 * (int64_t)p + k] = jacobi ? 1.0 / (1.0 + sqrt(Hp[7 * k])) : 1.0;
-        }
-        if (active[p]) {
-            const double* x = pose_ptr(pv, p, false);
-            if (first)
-                for (int k = 0; k < 7; ++k)
-                    xn += x[k] * x[k];
-            double ng[6], xp[7];
-            for (int k = 0; k < 6; ++k)
-                ng[k] = -g[6 * (int64_t)p + k];
-            pose_plus(x, ng, xp);
-            for (int k = 0; k < 7; ++k)
-                gm = fmax(gm, fabs(x[k] - xp[k]));
-        }
-    }
-    xn = block_sum(xn, sh);
-    gm = block_max(gm, sh);
-    if (tid == 0) {
-        const double cost = cost_slot[0];
-        ctl->x_cost = cost;
-        ctl->need_jacobian = 0;
-        ctl->num_jac_evals++;
-        if (first) {
-            ctl->first_eval = 0;
-            ctl->initial_cost = cost;
-            ctl->x_norm = sqrt(xn);
-            ctl->cur.iteration = 0;
-            ctl->cur.step_is_valid = 1;
-            ctl->cur.step_is_successful = 1;
-        }
-        ctl->cur.cost = cost;
-        ctl->cur.gradient_max_norm = gm;
-        if (!isfinite(cost)) {
-            ctl->done = 1;
-            ctl->termination = VMM_BA_FAILURE;
-        }
-    }
-}
-
-// FinalizeIterationAndCheckIfMinimizerCanContinue, then the first half of
-// LevenbergMarquardtStrategy::ComputeStep (the LM diagonal).
-__global__ __launch_bounds__(256) void k_lm_begin(LmCtl* ctl, int n_tan, const double* __restrict__ H,
-                                                  const double* __restrict__ scale, double* __restrict__ diag,
-                                                  double* __restrict__ D2, vmm_ba_iteration* __restrict__ trace)
+// First kernel of an iteration's control flow, one block:
+//  (a) if an evaluation at x just ran (TrustRegionMinimizer::IterationZero /
+//      EvaluateGradientAndJacobian): total cost, Jacobi scaling (first evaluation only), gradient
+//      max-norm |Plus(x,-g) - x|_inf, completion of the pending iteration record;
+//  (b) FinalizeIterationAndCheckIfMinimizerCanContinue: push the record, termination tests;
+//  (c) first half of LevenbergMarquardtStrategy::ComputeStep: the LM diagonal D^2.
+__global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, const double* __restrict__ src,
+                                                    double* __restrict__ dst, size_t small_count,
+                                                    const double* __restrict__ H, const double* __restrict__ g,
+                                                    const double* __restrict__ cost_slot,
+                                                    const double* __restrict__ pose_cost, int n_pose_cost,
+                                                    double* __restrict__ scale, int32_t* __restrict__ active,
+                                                    double* __restrict__ diag, double* __restrict__ D2,
+                                                    vmm_ba_iteration* __restrict__ trace)
 {
     if (ctl->done)
         return;
-    __shared__ int s_stop, s_reuse;
-    __shared__ double s_radius;
-    if (threadIdx.x == 0) {
-        vmm_ba_iteration cur = ctl->cur;
-        cur.trust_region_radius = ctl->radius;
-        if (cur.step_is_successful)
-            ctl->num_successful++;
-        else
-            ctl->num_unsuccessful++;
-        if (ctl->records < ctl->trace_capacity)
-            trace[ctl->records] = cur;
-        ctl->records++;
-        int stop = 0;
-        if (cur.iteration >= ctl->max_num_iterations) {
-            stop = 1;
-            ctl->termination = VMM_BA_NO_CONVERGENCE;
-        } else if (cur.step_is_successful && cur.gradient_max_norm <= ctl->gradient_tolerance) {
-            stop = 1;
-            ctl->termination = VMM_BA_CONVERGENCE;
-        } else if (ctl->radius <= ctl->min_radius) {
-            stop = 1;
-            ctl->termination = VMM_BA_CONVERGENCE;
+    __shared__ double sh[256];
+    __shared__ int s_stop, s_reuse, s_evaluated;
+    __shared__ double s_radius, s_lo, s_hi, s_xn, s_gm, s_cst;
+    const int tid = threadIdx.x;
+    const int n_pose = pv.n_cams + pv.n_tags;
+    const int n_tan = 6 * n_pose;
+    if (tid == 0)
+        s_evaluated = 0;
+    __syncthreads();
+    if (ctl->need_jacobian) {
+        // multi-GPU: the all-reduced staging buffer becomes the working copy
+        if (src != dst) {
+            for (size_t i = tid; i < small_count; i += 256)
+                dst[i] = src[i];
+            __syncthreads();
         }
-        if (stop) {
-            ctl->done = 1;
-        } else {
-            const double gmax = cur.gradient_max_norm;
-            vmm_ba_iteration z;
-            z.iteration = cur.iteration + 1;
-            z.step_is_valid = 0;
-            z.step_is_successful = 0;
-            z.reserved = 0;
-            z.cost = ctl->x_cost;
-            z.cost_change = 0.0;
-            z.gradient_max_norm = gmax;  // carried until the next successful step
-            z.step_norm = 0.0;
-            z.relative_decrease = 0.0;
-            z.trust_region_radius = 0.0;
-            z.model_cost_change = 0.0;
-            ctl->cur = z;
-            ctl->iteration = z.iteration;
-            ctl->lin_fail = 0;
-            ctl->num_lm_iterations++;
+        const bool first = ctl->first_eval != 0;
+        const bool jacobi = ctl->jacobi_scaling != 0;
+        double xn = 0.0, gm = 0.0, cst = 0.0;
+        for (int p = tid; p < n_pose; p += 256) {
+            const double* Hp = H + 36 * (int64_t)p;
+            if (first) {
+                // blocks with zero Jacobian columns (constant origin tag, poses without observations)
+                // are not part of Ceres' reduced program
+                active[p] = (Hp[0] + Hp[7] + Hp[14]) > 0.0 ? 1 : 0;
+                for (int k = 0; k < 6; ++k)
+                    scale[6 * (int64_t)p + k] = jacobi ? 1.0 / (1.0 + sqrt(Hp[7 * k])) : 1.0;
+            }
+            if (active[p]) {
+                const double* x = pose_ptr(pv, p, false);
+                if (first)
+                    for (int k = 0; k < 7; ++k)
+                        xn += x[k] * x[k];
+                double ng[6], xp[7];
+                for (int k = 0; k < 6; ++k)
+                    ng[k] = -g[6 * (int64_t)p + k];
+                pose_plus(x, ng, xp);
+                for (int k = 0; k < 7; ++k)
+                    gm = fmax(gm, fabs(x[k] - xp[k]));
+            }
+        }
+        // single GPU: per-pose costs of the eliminated family are summed here; world > 1: cost_slot
+        if (pose_cost)
+            for (int i = tid; i < n_pose_cost; i += 256)
+                cst += pose_cost[i];
+        xn = block_sum(xn, sh);
+        gm = block_max(gm, sh);
+        cst = pose_cost ? block_sum(cst, sh) : cost_slot[0];
+        s_xn = xn;
+        s_gm = gm;
+        s_cst = cst;
+        s_evaluated = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // one load and one store of the control block: field-by-field global accesses cost ~0.5 us each
+        LmCtl c = *ctl;
+        if (s_evaluated) {
+            const double cst = s_cst;
+            const bool first = c.first_eval != 0;
+            c.x_cost = cst;
+            c.need_jacobian = 0;
+            c.num_jac_evals++;
+            if (first) {
+                c.first_eval = 0;
+                c.initial_cost = cst;
+                c.x_norm = sqrt(s_xn);
+                c.cur.iteration = 0;
+                c.cur.step_is_valid = 1;
+                c.cur.step_is_successful = 1;
+            }
+            c.cur.cost = cst;
+            c.cur.gradient_max_norm = s_gm;
+            if (!isfinite(cst)) {
+                c.done = 1;
+                c.termination = VMM_BA_FAILURE;
+            }
+        }
+        int stop = c.done;
+        if (!stop) {
+            vmm_ba_iteration cur = c.cur;
+            cur.trust_region_radius = c.radius;
+            if (cur.step_is_successful)
+                c.num_successful++;
+            else
+                c.num_unsuccessful++;
+            if (c.records < c.trace_capacity)
+                trace[c.records] = cur;
+            c.records++;
+            if (cur.iteration >= c.max_num_iterations) {
+                stop = 1;
+                c.termination = VMM_BA_NO_CONVERGENCE;
+            } else if (cur.step_is_successful && cur.gradient_max_norm <= c.gradient_tolerance) {
+                stop = 1;
+                c.termination = VMM_BA_CONVERGENCE;
+            } else if (c.radius <= c.min_radius) {
+                stop = 1;
+                c.termination = VMM_BA_CONVERGENCE;
+            }
+            if (stop) {
+                c.done = 1;
+            } else {
+                vmm_ba_iteration z;
+                z.iteration = cur.iteration + 1;
+                z.step_is_valid = 0;
+                z.step_is_successful = 0;
+                z.reserved = 0;
+                z.cost = c.x_cost;
+                z.cost_change = 0.0;
+                z.gradient_max_norm = cur.gradient_max_norm;  // carried until the next successful step
+                z.step_norm = 0.0;
+                z.relative_decrease = 0.0;
+                z.trust_region_radius = 0.0;
+                z.model_cost_change = 0.0;
+                c.cur = z;
+                c.iteration = z.iteration;
+                c.lin_fail = 0;
+                c.num_lm_iterations++;
+            }
         }
         s_stop = stop;
-        s_reuse = ctl->reuse_diagonal;
-        s_radius = ctl->radius;
+        s_reuse = c.reuse_diagonal;
+        s_radius = c.radius;
+        s_lo = c.min_lm_diagonal;
+        s_hi = c.max_lm_diagonal;
         if (!stop)
-            ctl->reuse_diagonal = 1;
+            c.reuse_diagonal = 1;
+        *ctl = c;
     }
     __syncthreads();
     if (s_stop)
         return;
-    const double lo = ctl->min_lm_diagonal, hi = ctl->max_lm_diagonal;
-    for (int c = threadIdx.x; c < n_tan; c += 256) {
+    const double lo = s_lo, hi = s_hi;
+    for (int c = tid; c < n_tan; c += 256) {
         double d;
         if (!s_reuse) {
             const int p = c / 6, k = c % 6;
-            const double s = scale[c];
-            d = s * s * H[36 * (int64_t)p + 7 * k];   // squared column norm of the scaled Jacobian
+            const double sc = scale[c];
+            d = sc * sc * H[36 * (int64_t)p + 7 * k];   // squared column norm of the scaled Jacobian
             d = fmin(fmax(d, lo), hi);
             diag[c] = d;
         } else {
             d = diag[c];
         }
-        const double lm = sqrt(d / s_radius);         // lm_diagonal_ = sqrt(diagonal_ / radius_)
+        const double lm = sqrt(d / s_radius);           // lm_diagonal_ = sqrt(diagonal_ / radius_)
         D2[c] = lm * lm;
     }
 }
@@ -289,11 +309,15 @@ __global__ __launch_bounds__(256) void k_cross(const LmCtl* ctl, const Task* __r
         part[wave] = v;
 }
 
-// delta (unscaled tangent step) for every pose and the candidate x+ = Plus(x, delta).
-// TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost (first half).
+// delta (unscaled tangent step) for every pose, the candidate x+ = Plus(x, delta)
+// (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost, first half) and this pose's terms of
+// the model cost and of the step/parameter norms: pose_part[p] = { delta.g, delta^T H delta,
+// |x - x+|^2, |x+|^2, non-finite flag } (the last two only for active poses).
 __global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_pose, int f_off_pose,
                             const double* __restrict__ step_comm, const double* __restrict__ yf,
-                            const double* __restrict__ scale, double* __restrict__ delta)
+                            const double* __restrict__ scale, double* __restrict__ delta,
+                            const double* __restrict__ H, const double* __restrict__ g,
+                            const int32_t* __restrict__ active, double* __restrict__ pose_part)
 {
     if (ctl->done)
         return;
@@ -303,6 +327,7 @@ __global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_p
         return;
     const bool is_e = (p >= e_off_pose) && (p < e_off_pose + n_e);
     double d[6];
+    double bad = 0.0;
     for (int k = 0; k < 6; ++k) {
         if (ctl->lin_fail)
             d[k] = 0.0;
@@ -311,23 +336,47 @@ __global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_p
         else
             d[k] = -yf[6 * (int64_t)(p - f_off_pose) + k] * scale[6 * (int64_t)p + k];
         delta[6 * (int64_t)p + k] = d[k];
+        if (!isfinite(d[k]))
+            bad = 1.0;
     }
+    const double* x = pose_ptr(pv, p, false);
     double out[7];
-    pose_plus(pose_ptr(pv, p, false), d, out);
+    pose_plus(x, d, out);
     double* c = pose_ptr(pv, p, true);
-    for (int k = 0; k < 7; ++k)
+    double sn = 0.0, xn = 0.0;
+    for (int k = 0; k < 7; ++k) {
         c[k] = out[k];
+        const double df = x[k] - out[k];
+        sn += df * df;
+        xn += out[k] * out[k];
+    }
+    const double* Hp = H + 36 * (int64_t)p;
+    double gd = 0.0, quad = 0.0;
+    for (int a = 0; a < 6; ++a) {
+        gd += d[a] * g[6 * (int64_t)p + a];
+        double r = 0.0;
+        for (int b = 0; b < 6; ++b)
+            r += Hp[6 * a + b] * d[b];
+        quad += d[a] * r;
+    }
+    const bool act = active[p] != 0;
+    double* o = pose_part + 5 * (int64_t)p;
+    o[0] = gd;
+    o[1] = quad;
+    o[2] = act ? sn : 0.0;
+    o[3] = act ? xn : 0.0;
+    o[4] = bad;
 }
 
 // Step validation, convergence tests, acceptance and radius update:
 // ComputeTrustRegionStep (model cost), ParameterToleranceReached, FunctionToleranceReached,
 // IsStepSuccessful, HandleSuccessfulStep / HandleUnsuccessfulStep / HandleInvalidStep,
 // LevenbergMarquardtStrategy::StepAccepted / StepRejected.
-__global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const double* __restrict__ H,
-                                                const double* __restrict__ g, const double* __restrict__ delta,
-                                                const int32_t* __restrict__ active,
+__global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const double* __restrict__ pose_part,
                                                 const double* __restrict__ cross_slot,
-                                                const double* __restrict__ cand_cost_slot)
+                                                const double* __restrict__ cross_parts, int n_cross,
+                                                const double* __restrict__ cand_cost_slot,
+                                                const double* __restrict__ cost_parts, int n_cost)
 {
     if (ctl->done)
         return;
@@ -335,99 +384,98 @@ __global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const 
     __shared__ int s_accept;
     const int tid = threadIdx.x;
     const int n_pose = pv.n_cams + pv.n_tags;
-    double gd = 0.0, quad = 0.0, sn = 0.0, xn = 0.0, bad = 0.0;
+    double gd = 0.0, quad = 0.0, sn = 0.0, xn = 0.0, bad = 0.0, cross = 0.0, ccost = 0.0;
     for (int p = tid; p < n_pose; p += 256) {
-        const double* d = delta + 6 * (int64_t)p;
-        const double* Hp = H + 36 * (int64_t)p;
-        for (int a = 0; a < 6; ++a) {
-            if (!isfinite(d[a]))
-                bad = 1.0;
-            gd += d[a] * g[6 * (int64_t)p + a];
-            double r = 0.0;
-            for (int b = 0; b < 6; ++b)
-                r += Hp[6 * a + b] * d[b];
-            quad += d[a] * r;
-        }
-        if (active[p]) {
-            const double* x = pose_ptr(pv, p, false);
-            const double* c = pose_ptr(pv, p, true);
-            for (int k = 0; k < 7; ++k) {
-                const double df = x[k] - c[k];
-                sn += df * df;
-                xn += c[k] * c[k];
-            }
-        }
+        const double* o = pose_part + 5 * (int64_t)p;
+        gd += o[0];
+        quad += o[1];
+        sn += o[2];
+        xn += o[3];
+        bad = fmax(bad, o[4]);
     }
+    // single GPU: the wave partials of the cross term and of the candidate cost are summed here
+    // (fixed order); with world > 1 they were summed and all-reduced before (scalar slots)
+    if (cross_parts)
+        for (int i = tid; i < n_cross; i += 256)
+            cross += cross_parts[i];
+    if (cost_parts)
+        for (int i = tid; i < n_cost; i += 256)
+            ccost += cost_parts[i];
     gd = block_sum(gd, sh);
     quad = block_sum(quad, sh);
     sn = block_sum(sn, sh);
     xn = block_sum(xn, sh);
     bad = block_max(bad, sh);
+    cross = cross_parts ? block_sum(cross, sh) : cross_slot[0];
+    ccost = cost_parts ? block_sum(ccost, sh) : cand_cost_slot[0];
     if (tid == 0) {
+        // one load and one store of the control block (see k_iter_begin)
+        LmCtl c = *ctl;
         int accept = 0;
-        const bool lin_fail = ctl->lin_fail != 0 || bad != 0.0;
+        const bool lin_fail = c.lin_fail != 0 || bad != 0.0;
         // model_cost_change = -(J d)^T (r + J d / 2) = -d^T g - 1/2 d^T H d   (unscaled coordinates)
-        const double mcc = lin_fail ? 0.0 : -gd - 0.5 * (quad + 2.0 * cross_slot[0]);
-        ctl->model_cost_change = mcc;
-        ctl->cur.model_cost_change = mcc;
+        const double mcc = lin_fail ? 0.0 : -gd - 0.5 * (quad + 2.0 * cross);
+        c.model_cost_change = mcc;
+        c.cur.model_cost_change = mcc;
         const bool valid = !lin_fail && (mcc > 0.0);
-        ctl->cur.step_is_valid = valid ? 1 : 0;
+        c.cur.step_is_valid = valid ? 1 : 0;
         if (!valid) {
             // HandleInvalidStep
-            ctl->num_invalid++;
-            if (ctl->num_invalid >= ctl->max_invalid) {
-                ctl->done = 1;
-                ctl->termination = VMM_BA_FAILURE;
+            c.num_invalid++;
+            if (c.num_invalid >= c.max_invalid) {
+                c.done = 1;
+                c.termination = VMM_BA_FAILURE;
             } else {
-                ctl->radius = ctl->radius / ctl->decrease_factor;
-                ctl->decrease_factor *= 2.0;
-                ctl->reuse_diagonal = 1;
-                ctl->cur.cost = ctl->x_cost;
-                ctl->cur.step_is_successful = 0;
+                c.radius = c.radius / c.decrease_factor;
+                c.decrease_factor *= 2.0;
+                c.reuse_diagonal = 1;
+                c.cur.cost = c.x_cost;
+                c.cur.step_is_successful = 0;
             }
         } else {
-            ctl->num_invalid = 0;
-            double cand = cand_cost_slot[0];
-            ctl->num_cost_evals++;
+            c.num_invalid = 0;
+            double cand = ccost;
+            c.num_cost_evals++;
             if (!isfinite(cand))
                 cand = DBL_MAX;
-            ctl->cand_cost = cand;
+            c.cand_cost = cand;
             const double step_norm = sqrt(sn);
-            ctl->cur.step_norm = step_norm;
-            const double x_cost = ctl->x_cost;
+            c.cur.step_norm = step_norm;
+            const double x_cost = c.x_cost;
             const double cost_change = x_cost - cand;
-            if (step_norm <= ctl->parameter_tolerance * (ctl->x_norm + ctl->parameter_tolerance)) {
-                ctl->done = 1;   // ParameterToleranceReached: return without pushing this record
-                ctl->termination = VMM_BA_CONVERGENCE;
-            } else if (fabs(cost_change) <= ctl->function_tolerance * x_cost) {
-                ctl->cur.cost_change = cost_change;
-                ctl->done = 1;   // FunctionToleranceReached
-                ctl->termination = VMM_BA_CONVERGENCE;
+            if (step_norm <= c.parameter_tolerance * (c.x_norm + c.parameter_tolerance)) {
+                c.done = 1;   // ParameterToleranceReached: return without pushing this record
+                c.termination = VMM_BA_CONVERGENCE;
+            } else if (fabs(cost_change) <= c.function_tolerance * x_cost) {
+                c.cur.cost_change = cost_change;
+                c.done = 1;   // FunctionToleranceReached
+                c.termination = VMM_BA_CONVERGENCE;
             } else {
-                ctl->cur.cost_change = cost_change;
+                c.cur.cost_change = cost_change;
                 const double rd = (cand >= DBL_MAX) ? -DBL_MAX : cost_change / mcc;
-                ctl->cur.relative_decrease = rd;
-                if (rd > ctl->min_relative_decrease) {
+                c.cur.relative_decrease = rd;
+                if (rd > c.min_relative_decrease) {
                     accept = 1;
                     const double q = 2.0 * rd - 1.0;
                     double den = 1.0 - q * q * q;
                     den = den < 1.0 / 3.0 ? 1.0 / 3.0 : den;
-                    double r = ctl->radius / den;
-                    ctl->radius = r > ctl->max_radius ? ctl->max_radius : r;
-                    ctl->decrease_factor = 2.0;
-                    ctl->reuse_diagonal = 0;
-                    ctl->need_jacobian = 1;
-                    ctl->x_norm = sqrt(xn);
-                    ctl->cur.step_is_successful = 1;
+                    double r = c.radius / den;
+                    c.radius = r > c.max_radius ? c.max_radius : r;
+                    c.decrease_factor = 2.0;
+                    c.reuse_diagonal = 0;
+                    c.need_jacobian = 1;
+                    c.x_norm = sqrt(xn);
+                    c.cur.step_is_successful = 1;
                 } else {
-                    ctl->cur.step_is_successful = 0;
-                    ctl->cur.cost = cand;
-                    ctl->radius = ctl->radius / ctl->decrease_factor;
-                    ctl->decrease_factor *= 2.0;
-                    ctl->reuse_diagonal = 1;
+                    c.cur.step_is_successful = 0;
+                    c.cur.cost = cand;
+                    c.radius = c.radius / c.decrease_factor;
+                    c.decrease_factor *= 2.0;
+                    c.reuse_diagonal = 1;
                 }
             }
         }
+        *ctl = c;
         s_accept = accept;
     }
     __syncthreads();
@@ -469,16 +517,12 @@ void launch_zero_unless_eval(Engine& e, double* buf, size_t n)
     hipLaunchKernelGGL(k_zero_unless_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.ctl, buf, n);
 }
 
-void launch_post_eval(Engine& e, const double* src)
+void launch_iter_begin(Engine& e, const double* src)
 {
-    hipLaunchKernelGGL(k_post_eval, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), src, e.small, e.small_count,
-                       e.H_cam, e.g_cam, e.cost_slot, e.scale, e.active);
-}
-
-void launch_lm_begin(Engine& e)
-{
-    hipLaunchKernelGGL(k_lm_begin, dim3(1), dim3(256), 0, e.stream, e.ctl, 6 * (e.n_cams + e.n_tags), e.H_cam, e.scale,
-                       e.diag, e.D2, e.trace);
+    const bool single = e.world <= 1;
+    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), src, e.small, e.small_count,
+                       e.H_cam, e.g_cam, e.cost_slot, single ? e.part_cost : (const double*)nullptr, e.n_e, e.scale,
+                       e.active, e.diag, e.D2, e.trace);
 }
 
 void launch_backsub(Engine& e)
@@ -498,14 +542,16 @@ void launch_candidate(Engine& e)
     const int e_off = e.elim_cams ? 0 : e.n_cams;
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const int n_pose = e.n_cams + e.n_tags;
-    hipLaunchKernelGGL(k_candidate, dim3((n_pose + 127) / 128), dim3(128), 0, e.stream, e.ctl, views(e), e.n_e, e_off,
-                       f_off, e.step_comm, e.yf, e.scale, e.delta);
+    hipLaunchKernelGGL(k_candidate, dim3((n_pose + 63) / 64), dim3(64), 0, e.stream, e.ctl, views(e), e.n_e, e_off,
+                       f_off, e.step_comm, e.yf, e.scale, e.delta, e.H_cam, e.g_cam, e.active, e.pose_part);
 }
 
 void launch_decide(Engine& e)
 {
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), e.H_cam, e.g_cam, e.delta, e.active,
-                       e.step_comm + 6 * (size_t)e.n_e, e.cost_comm);
+    const bool single = e.world <= 1;
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), e.pose_part,
+                       e.step_comm + 6 * (size_t)e.n_e, single ? e.part_cross : (const double*)nullptr, e.ordE.n_tasks,
+                       e.cost_comm, single ? e.part_k1 : (const double*)nullptr, e.ordE.n_tasks);
 }
 
 } // namespace vmm

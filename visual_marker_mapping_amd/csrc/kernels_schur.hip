@@ -47,7 +47,8 @@ __device__ __forceinline__ bool chol6(double* A)
 __global__ void k_elim_factor(LmCtl* ctl, int n_e, int e_off_pose, const double* __restrict__ H_E,
                               const double* __restrict__ g_E, const double* __restrict__ scale,
                               const double* __restrict__ D2, double* __restrict__ Le,
-                              double* __restrict__ ze)
+                              double* __restrict__ ze, const int32_t* __restrict__ pose_task,
+                              double* __restrict__ Z, int ldz, int zcol)
 {
     if (ctl->done)
         return;
@@ -79,9 +80,14 @@ __global__ void k_elim_factor(LmCtl* ctl, int n_e, int e_off_pose, const double*
 #pragma unroll
     for (int k = 0; k < 36; ++k)
         Le[36 * (int64_t)e + k] = M[k];
+    // z column of the augmented Z (rhs of the eliminated block).  A pose is owned by the rank that
+    // holds its observations; elsewhere its rows of Z stay zero.
+    const bool owned = pose_task[e + 1] > pose_task[e];
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 6; ++k) {
         ze[6 * (int64_t)e + k] = v[k];
+        Z[(int64_t)(6 * e + k) * ldz + zcol] = owned ? v[k] : 0.0;
+    }
 }
 
 // One thread per observation (E order): Z block = L_e^{-1} (s_e W s_f) into the dense Z.
@@ -126,21 +132,6 @@ __global__ __launch_bounds__(256) void k_form_z(const LmCtl* ctl, int64_t n_obs,
 #pragma unroll
         for (int c = 0; c < 6; ++c)
             zrow[(int64_t)r * ldz + c] = X[6 * r + c];
-}
-
-// z column of the augmented Z: Z[6e+r][col] = z_e[r].
-// A pose is owned by the rank that holds its observations; elsewhere its rows of Z stay zero.
-__global__ void k_write_zcol(const LmCtl* ctl, int n_e, const int32_t* __restrict__ pose_task,
-                             const double* __restrict__ ze, double* __restrict__ Z, int ldz, int col)
-{
-    if (ctl->done)
-        return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 6 * n_e)
-        return;
-    const int e = i / 6;
-    const bool owned = pose_task[e + 1] > pose_task[e];
-    Z[(int64_t)i * ldz + col] = owned ? ze[i] : 0.0;
 }
 
 // ---- symmetric rank-k update on the f64 matrix cores --------------------------------------------
@@ -302,9 +293,18 @@ void launch_syrk_raw(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz,
 }
 
 // S = -(sum of slabs) over the lower block triangle (row blocks 0..n_blk incl. the rhs row block).
+struct DiagArgs {        // kept family's damped diagonal blocks and rhs, added in the same pass on one GPU
+    const double* H_F;
+    const double* g_F;
+    const double* scale_F;   // scale + 6 * f_off
+    const double* D2_F;      // D2 + 6 * f_off
+    int n_red, n_pad;
+};
+
+template <bool ADD_DIAG>
 __global__ __launch_bounds__(256) void k_reduce_slabs(const LmCtl* ctl, const double* __restrict__ slabs,
                                                       int split_k, size_t slab_stride, int ld, int n_rows,
-                                                      int n_cols, double* __restrict__ S)
+                                                      int n_cols, double* __restrict__ S, DiagArgs da)
 {
     if (ctl && ctl->done)
         return;
@@ -318,7 +318,21 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const LmCtl* ctl, const do
     double s = 0.0;
     for (int k = 0; k < split_k; ++k)
         s += slabs[(size_t)k * slab_stride + off];
-    S[off] = -s;
+    double v = -s;
+    if (ADD_DIAG) {
+        if (row == da.n_pad) {                       // rhs row: b = s_f g_f - Z^T z
+            if (col < da.n_red)
+                v += da.scale_F[col] * da.g_F[col];
+        } else if (row < da.n_red && col <= row && (row / 6) == (col / 6)) {
+            const int f = row / 6, a = row % 6, b = col % 6;
+            v += da.scale_F[row] * da.H_F[36 * (int64_t)f + 6 * a + b] * da.scale_F[col];
+            if (a == b)
+                v += da.D2_F[row];
+        } else if (row >= da.n_red && row < da.n_pad && col == row) {
+            v = 1.0;                                 // padding of the reduced system
+        }
+    }
+    S[off] = v;
 }
 
 // Adds the kept family's damped diagonal blocks and right-hand side (identical on every rank, so it
@@ -358,21 +372,20 @@ void launch_elim(Engine& e)
     const double* H_E = e.elim_cams ? e.H_cam : e.H_tag;
     const double* g_E = e.elim_cams ? e.g_cam : e.g_tag;
     hipLaunchKernelGGL(k_elim_factor, dim3((e.n_e + 63) / 64), dim3(64), 0, e.stream, e.ctl, e.n_e, e_off, H_E, g_E,
-                       e.scale, e.D2, e.Le, e.ze);
+                       e.scale, e.D2, e.Le, e.ze, e.ordE.pose_task, e.Z, e.ldz, e.n_pad);
     if (e.ordE.n > 0)
         hipLaunchKernelGGL(k_form_z, dim3((unsigned)((e.ordE.n + 255) / 256)), dim3(256), 0, e.stream, e.ctl,
                            e.ordE.n, e.ordE.n_pad, e.ordE.own, e.ordE.other, e.W, e.Le, e.scale, e_off, f_off,
                            e.Z, e.ldz);
-    hipLaunchKernelGGL(k_write_zcol, dim3((6 * e.n_e + 255) / 256), dim3(256), 0, e.stream, e.ctl, e.n_e,
-                       e.ordE.pose_task, e.ze, e.Z, e.ldz, e.n_pad);
 }
 
 void launch_reduce_slabs(hipStream_t st, const LmCtl* ctl, const double* slabs, int split_k, size_t slab_stride,
                          int ld, int n_rows, int n_cols, double* S)
 {
     const int64_t total = (int64_t)n_rows * n_cols;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctl, slabs, split_k,
-                       slab_stride, ld, n_rows, n_cols, S);
+    DiagArgs da = {};
+    hipLaunchKernelGGL((k_reduce_slabs<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctl, slabs,
+                       split_k, slab_stride, ld, n_rows, n_cols, S, da);
 }
 
 // slabs[s] = (Z^T Z)(K chunk s): row blocks 0..n_blk (the last one holds the rhs row), column blocks 0..n_blk-1
@@ -382,14 +395,33 @@ void launch_syrk_only(Engine& e)
                     e.ldz, (size_t)e.ldz * e.ldz, false);
 }
 
+// S = -(sum of slabs) [+ damped diagonal blocks and rhs on one GPU; with world > 1 they are added by
+// launch_add_diag after the all-reduce, being identical on every rank]
 void launch_syrk_reduced(Engine& e)
 {
     launch_syrk_only(e);
-    launch_reduce_slabs(e.stream, e.ctl, e.slabs, e.split_k, (size_t)e.ldz * e.ldz, e.ldz, e.n_pad + 1, e.n_pad, e.S);
+    if (e.world > 1) {
+        launch_reduce_slabs(e.stream, e.ctl, e.slabs, e.split_k, (size_t)e.ldz * e.ldz, e.ldz, e.n_pad + 1, e.n_pad,
+                            e.S);
+        return;
+    }
+    const int f_off = e.elim_cams ? e.n_cams : 0;
+    DiagArgs da;
+    da.H_F = e.elim_cams ? e.H_tag : e.H_cam;
+    da.g_F = e.elim_cams ? e.g_tag : e.g_cam;
+    da.scale_F = e.scale + 6 * (size_t)f_off;
+    da.D2_F = e.D2 + 6 * (size_t)f_off;
+    da.n_red = e.n_red;
+    da.n_pad = e.n_pad;
+    const int64_t total = (int64_t)(e.n_pad + 1) * e.n_pad;
+    hipLaunchKernelGGL((k_reduce_slabs<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e.stream, e.ctl,
+                       e.slabs, e.split_k, (size_t)e.ldz * e.ldz, e.ldz, e.n_pad + 1, e.n_pad, e.S, da);
 }
 
 void launch_add_diag(Engine& e)
 {
+    if (e.world <= 1)
+        return;   // folded into the slab reduction
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const double* H_F = e.elim_cams ? e.H_tag : e.H_cam;
     const double* g_F = e.elim_cams ? e.g_tag : e.g_cam;

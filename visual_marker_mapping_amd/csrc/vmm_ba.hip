@@ -150,19 +150,24 @@ static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
         launch_zero_unless_eval(e, e.small_stage, e.small_count);
         if ((rc = do_allreduce(e, e.small_stage, e.small_count))) return rc;
     }
-    launch_post_eval(e, e.world > 1 ? e.small_stage : e.small);
-    launch_lm_begin(e);
+    launch_iter_begin(e, e.world > 1 ? e.small_stage : e.small);
     launch_elim(e);
     launch_syrk_reduced(e);
     if ((rc = do_allreduce(e, e.S, (size_t)(e.n_pad + 1) * e.ldz))) return rc;
     launch_add_diag(e);
     launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
     launch_backsub(e);
-    launch_sum(e, true, e.part_cross, e.ordE.n_tasks, e.step_comm + 6 * (size_t)e.n_e);
-    if ((rc = do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1))) return rc;
+    if (e.world > 1) {
+        launch_sum(e, true, e.part_cross, e.ordE.n_tasks, e.step_comm + 6 * (size_t)e.n_e);
+        if ((rc = do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1))) return rc;
+    }
     launch_candidate(e);
-    launch_cost(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a, e.cost_comm);
-    if ((rc = do_allreduce(e, e.cost_comm, 1))) return rc;
+    if (e.world > 1) {
+        launch_cost(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a, e.cost_comm);
+        if ((rc = do_allreduce(e, e.cost_comm, 1))) return rc;
+    } else {
+        launch_cost_kernel(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a);   // summed by k_decide
+    }
     launch_decide(e);
     HIP_TRY(hipGetLastError());
     return VMM_BA_OK;
@@ -425,6 +430,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     const size_t n_part = (size_t)std::max<int>(e.ordE.n_tasks, e.n_e) + 1;
     if ((rc = dev_alloc(e, &e.part_cost, n_part))) return fail(rc);
     if ((rc = dev_alloc(e, &e.part_cross, n_part))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.part_k1, n_part))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.pose_part, (size_t)5 * n_pose))) return fail(rc);
     if ((rc = dev_alloc(e, &e.ctl, 1))) return fail(rc);
     if (hipHostMalloc((void**)&e.ctl_host, sizeof(LmCtl)) != hipSuccess) {
         set_error("hipHostMalloc failed");
