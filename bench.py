@@ -76,8 +76,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # VMM_BA_FORCE_COLLECTIVES=1 (test hook) runs the multi-rank code path with a single rank
+    use_dist = world > 1 or os.environ.get("VMM_BA_FORCE_COLLECTIVES") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     overrides = {}
@@ -93,14 +98,14 @@ def main():
                             s.obs_tag[idx], s.obs_px[idx], device=local_rank, elimination=elim, rank=rank,
                             world_size=world)
     setup_s = time.time() - t0
-    if world > 1:
+    if use_dist:
         ba.set_allreduce(vdist.make_allreduce(local_rank))
     robust = 1 if s.robustify else 0
     opts_kw = dict(robustify=robust, poll_interval=a.poll)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -111,7 +116,7 @@ def main():
     done, evals, solves, last = run_steps(ba, eng, s, opts_kw, a.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -138,7 +143,7 @@ def main():
             "residual_evals_per_sec": res_evals_per_s,
             "setup_s": setup_s,
         }
-    if world == 1:
+    if world == 1 and not use_dist:
         ba.set_state(s.cam_init, s.tag_init)
         kt = ba.time_kernels(eng.default_options(**opts_kw), reps=10)
         n_obs = kt["n_obs"]
@@ -204,7 +209,7 @@ def main():
                                               "by oracle/liboracle.so (C + OpenMP, Schur elimination of the same "
                                               "family); Ceres itself is not installable here" % (cpu_iters, dt)}
     ba.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -64,3 +64,47 @@ def test_two_ranks_match_one_rank(tmp_path, elim):
     np.testing.assert_allclose(r0["cam"], cam, rtol=0, atol=1e-10 * np.abs(cam).max())
     np.testing.assert_allclose(r0["tag"], tag, rtol=0, atol=1e-10 * np.abs(tag).max())
     np.testing.assert_allclose(float(r0["cost"]), float(r0["final"]), rtol=1e-12)
+
+
+def _nccl_worker(rank, world, port, out):
+    """One rank on the RCCL backend with the collective path forced on: exercises exactly what
+    bench.py --gpus N runs per rank (ExternalStream, zero-copy tensor view of the device buffer,
+    dist.all_reduce on the engine's stream); with one rank every all-reduce is the identity."""
+    import torch
+    import torch.distributed as dist
+    os.environ["VMM_BA_FORCE_COLLECTIVES"] = "1"
+    from visual_marker_mapping_amd import distributed as vd
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+    s = make_scene(1)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                            s.obs_px, device=0, rank=0, world_size=1)
+    ba.set_allreduce(vd.make_allreduce(0))
+    o = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+    cam, tag = ba.get_state()
+    ba.close()
+    np.savez(out, cam=cam, tag=tag, iters=o["iterations"], costs=[t["cost"] for t in o["trace"]])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_allreduce_hook_single_rank(tmp_path):
+    mp = pytest.importorskip("torch.multiprocessing")
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    out = str(tmp_path / "nccl.npz")
+    mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    s = make_scene(1)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                            s.obs_px)
+    ref = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+    cam, tag = ba.get_state()
+    ba.close()
+    r = np.load(out)
+    assert int(r["iters"]) == ref["iterations"]
+    np.testing.assert_allclose(r["costs"], [t["cost"] for t in ref["trace"]], rtol=1e-12)
+    np.testing.assert_allclose(r["cam"], cam, rtol=0, atol=1e-12 * np.abs(cam).max())
+    np.testing.assert_allclose(r["tag"], tag, rtol=0, atol=1e-12 * np.abs(tag).max())

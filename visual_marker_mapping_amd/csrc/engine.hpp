@@ -66,6 +66,7 @@ struct Engine {
     int device = 0;
     hipStream_t stream = nullptr;
     int rank = 0, world = 1;
+    bool multi = false;             // world > 1 (or forced for tests): staging buffers, eager launches, all-reduces
     vmm_ba_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
 

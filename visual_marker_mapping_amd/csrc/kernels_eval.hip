@@ -407,7 +407,7 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
                        e.n_e, e.ordE.pose_task, e.ordE.part, H_E, g_E, e.part_cost /* per-pose cost */);
     hipLaunchKernelGGL(k_reduce_pose, dim3((e.n_f * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
                        e.n_f, e.ordF.pose_task, e.ordF.part, H_F, g_F, (double*)nullptr);
-    if (e.world > 1 || !use_ctl)   // single-GPU solves sum the pose costs in k_iter_begin
+    if (e.multi || !use_ctl)   // single-GPU solves sum the pose costs in k_iter_begin
         hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1, e.ev_cost);
 }
 

@@ -519,7 +519,7 @@ void launch_zero_unless_eval(Engine& e, double* buf, size_t n)
 
 void launch_iter_begin(Engine& e, const double* src)
 {
-    const bool single = e.world <= 1;
+    const bool single = !e.multi;
     hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), src, e.small, e.small_count,
                        e.H_cam, e.g_cam, e.cost_slot, single ? e.part_cost : (const double*)nullptr, e.n_e, e.scale,
                        e.active, e.diag, e.D2, e.trace);
@@ -548,7 +548,7 @@ void launch_candidate(Engine& e)
 
 void launch_decide(Engine& e)
 {
-    const bool single = e.world <= 1;
+    const bool single = !e.multi;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), e.pose_part,
                        e.step_comm + 6 * (size_t)e.n_e, single ? e.part_cross : (const double*)nullptr, e.ordE.n_tasks,
                        e.cost_comm, single ? e.part_k1 : (const double*)nullptr, e.ordE.n_tasks);

@@ -400,7 +400,7 @@ void launch_syrk_only(Engine& e)
 void launch_syrk_reduced(Engine& e)
 {
     launch_syrk_only(e);
-    if (e.world > 1) {
+    if (e.multi) {
         launch_reduce_slabs(e.stream, e.ctl, e.slabs, e.split_k, (size_t)e.ldz * e.ldz, e.ldz, e.n_pad + 1, e.n_pad,
                             e.S);
         return;
@@ -420,7 +420,7 @@ void launch_syrk_reduced(Engine& e)
 
 void launch_add_diag(Engine& e)
 {
-    if (e.world <= 1)
+    if (!e.multi)
         return;   // folded into the slab reduction
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const double* H_F = e.elim_cams ? e.H_tag : e.H_cam;

@@ -110,7 +110,7 @@ static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx
 
 static int do_allreduce(Engine& e, double* buf, size_t count)
 {
-    if (e.world <= 1)
+    if (!e.multi)
         return VMM_BA_OK;
     if (!e.allreduce) {
         set_error("world_size > 1 but no all-reduce callback was set (vmm_ba_set_allreduce)");
@@ -146,23 +146,23 @@ static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
 {
     int rc;
     launch_eval_passes(e, true, o.robustify, o.huber_a, true);
-    if (e.world > 1) {
+    if (e.multi) {
         launch_zero_unless_eval(e, e.small_stage, e.small_count);
         if ((rc = do_allreduce(e, e.small_stage, e.small_count))) return rc;
     }
-    launch_iter_begin(e, e.world > 1 ? e.small_stage : e.small);
+    launch_iter_begin(e, e.multi ? e.small_stage : e.small);
     launch_elim(e);
     launch_syrk_reduced(e);
     if ((rc = do_allreduce(e, e.S, (size_t)(e.n_pad + 1) * e.ldz))) return rc;
     launch_add_diag(e);
     launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
     launch_backsub(e);
-    if (e.world > 1) {
+    if (e.multi) {
         launch_sum(e, true, e.part_cross, e.ordE.n_tasks, e.step_comm + 6 * (size_t)e.n_e);
         if ((rc = do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1))) return rc;
     }
     launch_candidate(e);
-    if (e.world > 1) {
+    if (e.multi) {
         launch_cost(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a, e.cost_comm);
         if ((rc = do_allreduce(e, e.cost_comm, 1))) return rc;
     } else {
@@ -178,7 +178,7 @@ static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
 // sequence is enqueued eagerly.
 static int run_iteration(Engine& e, const vmm_ba_options& o)
 {
-    if (e.world > 1 || !e.use_graph)
+    if (e.multi || !e.use_graph)
         return enqueue_iteration(e, o);
     if (!e.iter_graph || e.graph_robustify != o.robustify || e.graph_huber_a != o.huber_a) {
         if (e.iter_graph) {
@@ -331,6 +331,10 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     }
     e.rank = co.rank;
     e.world = co.world_size;
+    e.multi = e.world > 1;
+    if (const char* fw = getenv("VMM_BA_FORCE_COLLECTIVES"))
+        if (fw[0] == '1')
+            e.multi = true;   // test hook: one rank, but staging buffers + eager launches + all-reduce callbacks
     {
         const char* ng = getenv("VMM_BA_NO_GRAPH");
         e.use_graph = !(ng && ng[0] == '1');
@@ -383,7 +387,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.g_cam = e.H_tag + (size_t)36 * e.n_tags;
     e.g_tag = e.g_cam + (size_t)6 * e.n_cams;
     e.cost_slot = e.g_tag + (size_t)6 * e.n_tags;
-    if (e.world > 1) {
+    if (e.multi) {
         if ((rc = dev_alloc(e, &e.small_stage, e.small_count))) return fail(rc);
     } else {
         e.small_stage = e.small;
@@ -845,7 +849,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
         return VMM_BA_ERR_ARGUMENT;
     }
     Engine& e = *reinterpret_cast<Engine*>(h);
-    if (e.world > 1) {
+    if (e.multi) {
         set_error("time_kernels is a single-GPU diagnostic");
         return VMM_BA_ERR_STATE;
     }
