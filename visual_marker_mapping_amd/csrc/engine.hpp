@@ -108,7 +108,8 @@ struct Engine {
     int n_red = 0, n_pad = 0, ldz = 0, n_blk = 0;   // reduced order, padded, leading dim, blocks
     double* slabs = nullptr;        // [split_k][ldz*ldz]
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
-    double* P = nullptr;            // [kNB][ldz] transposed Cholesky panel
+    double* P = nullptr;            // [2][kNB][ldz] transposed Cholesky panels (alternating)
+    double* P2[2] = { nullptr, nullptr };
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
     unsigned* flags = nullptr;      // [256] hand-off flags of the chained back-substitution + [1] epoch word
     bool no_chain = false;          // VMM_BA_NO_CHAIN=1: per-block back-substitution kernels

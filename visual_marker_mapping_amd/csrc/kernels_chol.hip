@@ -155,8 +155,9 @@ __device__ __forceinline__ void panel_round(const int w, const int lane,
 
 template <bool HAS_T>
 __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
-                                           double* __restrict__ P, double* __restrict__ dinv, double* RA,
-                                           double* Pd, double* Pt, double* invd)
+                                           double* __restrict__ P, const double* __restrict__ Pprev,
+                                           double* __restrict__ dinv, double* RA, double* Pd, double* Pt,
+                                           double* invd, double* Ads, double* Ats)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,6 +182,44 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
                 const int grow = (R0 + row <= n_pad) ? R0 + row : n_pad;   // clamp: always in bounds
                 const double tv = S[(int64_t)grow * ld + K0 + 16 * tj + fr];
                 Tacc[tj][r] = (R0 + row <= n_pad) ? tv : 0.0;
+            }
+        }
+    }
+    // Look-ahead: the trailing update of panel k-1 skips block column k (k_chol_update starts at column
+    // k+1 of ITS panel), so this kernel does not have to wait for it; the missing rank-64 update of the
+    // tiles (k,k) and (i,k) is applied here from the previous transposed panel Pprev (64 x ld).
+    if (Pprev) {
+        // stage Pprev[:, K0..K0+63] (diagonal rows; also the B operand) and Pprev[:, R0..R0+63] k-major
+        double2 va[8], vt[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int mm = idx >> 5, c = (idx & 31) * 2;
+            va[it] = *reinterpret_cast<const double2*>(Pprev + (int64_t)mm * ld + K0 + c);
+            if (HAS_T)
+                vt[it] = *reinterpret_cast<const double2*>(Pprev + (int64_t)mm * ld + R0 + c);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int mm = idx >> 5, c = (idx & 31) * 2;
+            *reinterpret_cast<double2*>(&Ads[mm * kLdsRow + c]) = va[it];
+            if (HAS_T)
+                *reinterpret_cast<double2*>(&Ats[mm * kLdsRow + c]) = vt[it];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const int row = (ks * 4 + fk) * kLdsRow;
+            const double ad = -Ads[row + 16 * w + fr];
+            const double at = HAS_T ? -Ats[row + 16 * w + fr] : 0.0;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                const double b = Ads[row + 16 * tj + fr];
+                const double adm = (tj <= w) ? ad : 0.0;
+                Dacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(adm, b, Dacc[tj], 0, 0, 0);
+                if (HAS_T)
+                    Tacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, b, Tacc[tj], 0, 0, 0);
             }
         }
     }
@@ -235,19 +274,24 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
     STAMP(5);
 }
 
-__global__ __launch_bounds__(256) void k_chol_panel(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad,
-                                                    int k, double* __restrict__ P, double* __restrict__ dinv)
+constexpr int kPanelSmem = 64 * kLdT + 4 * 64 * kPs + 64 + 2 * 64 * kLdsRow;   // doubles
+constexpr int kUpdateSmem = 2 * 64 * kLdsRow;
+constexpr int kStepSmem = kPanelSmem > kUpdateSmem ? kPanelSmem : kUpdateSmem;
+
+__device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
+                                              double* __restrict__ P, const double* __restrict__ Pprev,
+                                              double* __restrict__ dinv, double* smem)
 {
-    if (ctl->done || ctl->lin_fail)
-        return;
-    __shared__ double RA[64 * kLdT];   // workgroup 0: L^T (stride kLdT); others: result tile R (stride kLd)
-    __shared__ double Pd[2 * 64 * kPs];
-    __shared__ double Pt[2 * 64 * kPs];
-    __shared__ double invd[64];
+    double* RA = smem;                     // workgroup 0: L^T (stride kLdT); others: result tile R (stride kLd)
+    double* Pd = RA + 64 * kLdT;
+    double* Pt = Pd + 2 * 64 * kPs;
+    double* invd = Pt + 2 * 64 * kPs;
+    double* Ads = invd + 64;               // previous panel, diagonal rows (k-major); 16-byte aligned offsets
+    double* Ats = Ads + 64 * kLdsRow;      // previous panel, this workgroup's rows
     if (blockIdx.x == 0)
-        panel_body<false>(ctl, S, ld, n_pad, k, P, dinv, RA, Pd, Pt, invd);
+        panel_body<false>(ctl, S, ld, n_pad, k, P, Pprev, dinv, RA, Pd, Pt, invd, Ads, Ats);
     else
-        panel_body<true>(ctl, S, ld, n_pad, k, P, dinv, RA, Pd, Pt, invd);
+        panel_body<true>(ctl, S, ld, n_pad, k, P, Pprev, dinv, RA, Pd, Pt, invd, Ads, Ats);
 }
 
 #ifdef VMM_STAMPS
@@ -257,24 +301,24 @@ extern "C" int vmm_ba_debug_read_stamps(unsigned long long* out, int n)
 }
 #endif
 
-// Trailing update of block column k: A_ij -= L_ik L_jk^T for k < j <= i (the rhs row block included)
+// Trailing update of block column k: A_ij -= L_ik L_jk^T for k+1 < j <= i (the rhs row block included;
+// block column k+1 is left to the next panel kernel, see the look-ahead note there)
 // with K = 64 taken from the transposed panel P (64 x ld, row m = panel column m).  One workgroup per
 // 64x64 tile; the whole K extent of both operands (2 x 32 KB) and the C tile are requested up front
 // so the kernel pays one memory latency, then 16 k-steps of four v_mfma_f64_16x16x4_f64 per wave.
-__global__ __launch_bounds__(256) void k_chol_update(const LmCtl* ctl, double* __restrict__ S, int ld, int n_blk,
-                                                     int k, const double* __restrict__ P)
+__device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, int n_blk, int k, int t,
+                                               const double* __restrict__ P, double* smem)
 {
-    if (ctl->done || ctl->lin_fail)
-        return;
-    __shared__ __attribute__((aligned(16))) double As[64 * kLdsRow];
-    __shared__ __attribute__((aligned(16))) double Bs[64 * kLdsRow];
-    // tile index -> (bi, bj): rows k+1..n_blk, columns k+1..min(bi, n_blk-1)
-    int t = blockIdx.x, bi = k + 1, bj = k + 1;
-    for (int r = k + 1; r <= n_blk; ++r) {
-        const int cnt = ((r < n_blk) ? r : n_blk - 1) - k;
+    double* As = smem;
+    double* Bs = smem + 64 * kLdsRow;
+    // tile index -> (bi, bj): columns k+2..min(bi, n_blk-1) (block column k+1 is updated lazily by the
+    // panel of that column), rows k+2..n_blk
+    int bi = k + 2, bj = k + 2;
+    for (int r = k + 2; r <= n_blk; ++r) {
+        const int cnt = ((r < n_blk) ? r : n_blk - 1) - (k + 1);
         if (t < cnt) {
             bi = r;
-            bj = k + 1 + t;
+            bj = k + 2 + t;
             break;
         }
         t -= cnt;
@@ -512,20 +556,41 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     }
 }
 
+// One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their
+// own column from panel k-1), the others apply the trailing update of panel k-1 to the columns >= k+1.
+// The two parts touch disjoint tiles and both only need results of the previous launch, so the update
+// (throughput work) runs beside the latency-bound panel instead of in front of it.
+__global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int n_blk,
+                                                   int k, int n_panel, double* __restrict__ Pcur,
+                                                   const double* __restrict__ Pprev, double* __restrict__ dinv)
+{
+    if (ctl->done || ctl->lin_fail)
+        return;
+    __shared__ __attribute__((aligned(16))) double smem[kStepSmem];
+    if ((int)blockIdx.x < n_panel)
+        chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, dinv, smem);
+    else
+        chol_update_wg(S, ld, n_blk, k - 1, (int)blockIdx.x - n_panel, Pprev, smem);
+}
+
+static int update_tiles(int n_blk, int k)   // tiles of the trailing update of panel k: columns >= k+2
+{
+    int tiles = 0;
+    for (int r = k + 2; r <= n_blk; ++r)
+        tiles += ((r < n_blk) ? r : n_blk - 1) - (k + 1);
+    return tiles;
+}
+
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl)
 {
     const int n_blk = n_pad / kNB;
     for (int k = 0; k < n_blk; ++k) {
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
-        const int wgs = 1 + (rows_below + 63) / 64;
-        hipLaunchKernelGGL(k_chol_panel, dim3(wgs), dim3(256), 0, e.stream, ctl, S, ld, n_pad, k, e.P, e.dinv);
-        // trailing update on block rows k+1..n_blk (rhs row block included), block cols k+1..n_blk-1
-        if (k + 1 < n_blk) {
-            int tiles = 0;
-            for (int r = k + 1; r <= n_blk; ++r)
-                tiles += ((r < n_blk) ? r : n_blk - 1) - k;
-            hipLaunchKernelGGL(k_chol_update, dim3(tiles), dim3(256), 0, e.stream, ctl, S, ld, n_blk, k, e.P);
-        }
+        const int n_panel = 1 + (rows_below + 63) / 64;
+        const int n_upd = k > 0 ? update_tiles(n_blk, k - 1) : 0;
+        hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, k,
+                           n_panel, e.P2[k & 1], k > 0 ? (const double*)e.P2[(k - 1) & 1] : (const double*)nullptr,
+                           e.dinv);
     }
     // one chained launch while every workgroup of the chain can be resident; the per-block kernels otherwise
     if (n_blk <= 200 && e.flags && !e.no_chain) {

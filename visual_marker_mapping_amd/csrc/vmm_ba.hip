@@ -108,6 +108,15 @@ static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx
     return VMM_BA_OK;
 }
 
+// the two alternating transposed-panel buffers of the look-ahead Cholesky; P must be allocated
+static int setup_lookahead(Engine& e, int n_blk_max, int ld)
+{
+    (void)n_blk_max;
+    e.P2[0] = e.P;
+    e.P2[1] = e.P + (size_t)kNB * ld;
+    return VMM_BA_OK;
+}
+
 static int do_allreduce(Engine& e, double* buf, size_t count)
 {
     if (!e.multi)
@@ -425,7 +434,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.Z, (size_t)e.k_pad * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.slabs, (size_t)e.split_k * e.ldz * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
-    if ((rc = dev_alloc(e, &e.P, (size_t)kNB * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * e.ldz))) return fail(rc);
+    if ((rc = setup_lookahead(e, e.n_blk, e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.flags, 260))) return fail(rc);
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
@@ -733,7 +743,8 @@ static int make_scratch(Engine& e, int device, int ld)
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
     int rc;
-    if ((rc = dev_alloc(e, &e.P, (size_t)kNB * ld))) return rc;
+    if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * ld))) return rc;
+    if ((rc = setup_lookahead(e, ld / kNB, ld))) return rc;
     if ((rc = dev_alloc(e, &e.dinv, (size_t)ld + kNB))) return rc;
     if ((rc = dev_alloc(e, &e.flags, 260))) return rc;
     { const char* nc = getenv("VMM_BA_NO_CHAIN"); e.no_chain = nc && nc[0] == '1'; }
