@@ -66,6 +66,23 @@ def test_blocked_cholesky_solve_matches_numpy(eng):
         np.testing.assert_allclose(x, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
 
 
+def test_cholesky_solve_is_repeatable(eng):
+    """The factorisation runs 19+ dependent launches and a flag-chained back-substitution: repeat it to
+    catch any ordering hazard (every run must give the same bits)."""
+    rng = np.random.default_rng(5)
+    n = 700
+    B = rng.standard_normal((n, n))
+    A = B @ B.T + n * np.eye(n)
+    b = rng.standard_normal(n)
+    x0, info0 = eng.dense_spd_solve(A, b)
+    assert info0 == 0
+    np.testing.assert_allclose(x0, np.linalg.solve(A, b), rtol=0, atol=1e-10 * np.abs(x0).max())
+    for _ in range(40):
+        x, info = eng.dense_spd_solve(A, b)
+        assert info == 0
+        np.testing.assert_array_equal(x, x0)
+
+
 def test_cholesky_reports_indefinite_matrix(eng):
     A = np.eye(70)
     A[50, 50] = -1.0

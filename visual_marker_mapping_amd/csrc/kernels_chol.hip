@@ -24,7 +24,7 @@ namespace vmm {
 __device__ unsigned long long g_stamps[32];
 #define STAMP(slot)                                                                  \
     do {                                                                             \
-        if (blockIdx.x == 1 && threadIdx.x == 0 && k == 0) {                         \
+        if (blockIdx.x == 1 && threadIdx.x == 0 && k == 1) {                         \
             g_stamps[slot] = __builtin_amdgcn_s_memtime();                           \
             g_stamps[16 + slot] = __builtin_amdgcn_s_memrealtime();                  \
         }                                                                            \
@@ -188,6 +188,7 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
     // Look-ahead: the trailing update of panel k-1 skips block column k (k_chol_update starts at column
     // k+1 of ITS panel), so this kernel does not have to wait for it; the missing rank-64 update of the
     // tiles (k,k) and (i,k) is applied here from the previous transposed panel Pprev (64 x ld).
+    STAMP(6);
     if (Pprev) {
         // stage Pprev[:, K0..K0+63] (diagonal rows; also the B operand) and Pprev[:, R0..R0+63] k-major
         double2 va[8], vt[8];
