@@ -46,19 +46,66 @@ __device__ unsigned long long g_stamps[32];
 #include "potrf64.inc"
 namespace vmm {
 
+// NOTE on the diagonal factor: L_kk goes to its own buffer Ld[k][64][64], never back into S(k,k): every
+// workgroup of the launch reads S(k,k) when it starts, and a workgroup that starts late (busy GPU, more
+// workgroups than CUs) must still find the unfactored block there.
+//
 // Panel of block column k as ONE right-looking factorisation of the tall matrix [A_kk; A_ik]:
 // workgroup 0 owns only the diagonal block, workgroup b >= 1 the diagonal block (re-factored
 // redundantly, cheaper than a dependent launch) plus 64 rows below it (the rhs row n_pad is just one
 // more row).  Both 64x64 blocks live in v_mfma_f64_16x16x4_f64 accumulators for the whole kernel:
 // wave w holds the 16-row tile row w (tiles (w,0..3); for the diagonal block only tj <= w).
-// Sixteen rounds of four columns:
-//   1. the lanes that hold columns j0..j0+3 publish them to a small LDS panel buffer
-//   2. wave 0 (diagonal rows) and wave 1 (rows below) each factor the 4x4 pivot block in registers
-//      and scale "their" row: x = a L4^{-T}, written back in place
-//   3. every wave applies the rank-4 update C -= X X_d^T to its tiles with one MFMA per tile
+// Eight rounds of eight columns:
+//   1. the lanes that hold columns J0..J0+7 publish them to a small LDS panel buffer
+//   2. wave 0 (diagonal rows) and wave 1 (rows below) each factor the 8x8 pivot block in registers
+//      (eight dependent rsqrt chains, no barrier in between) and scale "their" row: x = a L8^{-T},
+//      written back in place
+//   3. every wave applies the rank-8 update C -= X X_d^T to its tiles with two MFMAs per tile
 // The panel buffers ping-pong between rounds, so two barriers per round suffice and there is no
 // separate triangular-solve phase: after the last round the scaled columns ARE L_ik.
-constexpr int kPs = 5;   // LDS row stride (doubles) of the 64x4 panel buffers: conflict-free rows
+// (Four columns per round cost 16 x (2 barriers + 2 LDS round trips); eight halve that overhead for
+// the same pivot chain.)
+constexpr int kPs = 9;   // LDS row stride (doubles) of the 64x8 panel buffers: conflict-free rows
+constexpr int kPw = 8;   // columns per round
+
+__device__ __forceinline__ constexpr int tri8(int r, int c) { return r * (r + 1) / 2 + c; }
+
+struct Piv8 {
+    double l[36];     // lower triangle of the 8x8 factor, packed row-major (diagonal included)
+    double inv[8];    // reciprocals of its diagonal
+    bool ok;
+};
+
+// Cholesky of the symmetric 8x8 block at D (LDS, row stride kPs, lower triangle), in registers.
+__device__ __forceinline__ void chol8(const double* __restrict__ D, Piv8& p)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c)
+            p.l[tri8(r, c)] = D[r * kPs + c];
+    p.ok = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double t = p.l[tri8(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k)
+            t -= p.l[tri8(j, k)] * p.l[tri8(j, k)];
+        bool okj = true;
+        const double inv = safe_rsqrt(t, okj);
+        p.ok = p.ok && okj;
+        p.inv[j] = inv;
+        p.l[tri8(j, j)] = (okj ? t : 1.0) * inv;
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) {
+            double v = p.l[tri8(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k)
+                v -= p.l[tri8(i, k)] * p.l[tri8(j, k)];
+            p.l[tri8(i, j)] = v * inv;
+        }
+    }
+}
 
 template <int J0, bool HAS_T>
 __device__ __forceinline__ void panel_round(const int w, const int lane,
@@ -68,11 +115,10 @@ __device__ __forceinline__ void panel_round(const int w, const int lane,
 {
     constexpr int tc = J0 >> 4, cj = J0 & 15;
     const int fr = lane & 15, fk = lane >> 4;
-    double* pd = Pd + ((J0 >> 2) & 1) * 64 * kPs;
-    double* pt = Pt + ((J0 >> 2) & 1) * 64 * kPs;
-    RSTAMP(6);
-    // 1. publish columns J0..J0+3 (rows of my tile row) from the accumulators
-    if (fr >= cj && fr < cj + 4) {
+    double* pd = Pd + ((J0 >> 3) & 1) * 64 * kPs;
+    double* pt = Pt + ((J0 >> 3) & 1) * 64 * kPs;
+    // 1. publish columns J0..J0+7 (rows of my tile row) from the accumulators
+    if (fr >= cj && fr < cj + kPw) {
         const int q = fr - cj;
         const int row = 16 * w + fk;
         if (w >= tc) {
@@ -88,76 +134,94 @@ __device__ __forceinline__ void panel_round(const int w, const int lane,
             pt[(row + 12) * kPs + q] = Tacc[tc][3];
         }
     }
-    RSTAMP(7);
     __syncthreads();
-    RSTAMP(8);
     // 2. pivot block + row scaling (wave 0: diagonal rows, wave 1: rows below)
     if (w == 0 || (w == 1 && HAS_T)) {
-        const double* D = pd + J0 * kPs;
         double* row = (w == 0 ? pd : pt) + lane * kPs;
-        const double r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-        Piv4 p;
-        chol4(D[0], D[kPs], D[kPs + 1], D[2 * kPs], D[2 * kPs + 1], D[2 * kPs + 2], D[3 * kPs], D[3 * kPs + 1],
-              D[3 * kPs + 2], D[3 * kPs + 3], p);
-        const double x0 = r0 * p.i0;
-        const double x1 = (r1 - x0 * p.l10) * p.i1;
-        const double x2 = (r2 - x0 * p.l20 - x1 * p.l21) * p.i2;
-        const double x3 = (r3 - x0 * p.l30 - x1 * p.l31 - x2 * p.l32) * p.i3;
+        double x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            x[q] = row[q];
+        Piv8 p;
+        chol8(pd + J0 * kPs, p);
+        // x = a L8^{-T}
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            double v = x[q];
+#pragma unroll
+            for (int k = 0; k < q; ++k)
+                v -= x[k] * p.l[tri8(q, k)];
+            x[q] = v * p.inv[q];
+        }
         if (w == 0) {
             ok = ok && p.ok;
             const int r = lane - J0;
-            const bool below = r >= 4;
+            const bool below = r >= kPw, above = r < 0;
             if (below) {
-                row[0] = x0; row[1] = x1; row[2] = x2; row[3] = x3;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    row[q] = x[q];
             }
             if (!HAS_T) {
                 // keep L^T for the write-back: x below the pivot block, the factor inside, zero above
-                const bool above = r < 0;
-                At[(J0 + 0) * kLdT + lane] = below ? x0 : (above ? 0.0 : (r == 0 ? p.d0 : (r == 1 ? p.l10 : (r == 2 ? p.l20 : p.l30))));
-                At[(J0 + 1) * kLdT + lane] = below ? x1 : (above ? 0.0 : (r == 1 ? p.d1 : (r == 2 ? p.l21 : (r == 3 ? p.l31 : 0.0))));
-                At[(J0 + 2) * kLdT + lane] = below ? x2 : (above ? 0.0 : (r == 2 ? p.d2 : (r == 3 ? p.l32 : 0.0)));
-                At[(J0 + 3) * kLdT + lane] = below ? x3 : (above ? 0.0 : (r == 3 ? p.d3 : 0.0));
-                if (r >= 0 && r < 4)
-                    invd[lane] = r == 0 ? p.i0 : (r == 1 ? p.i1 : (r == 2 ? p.i2 : p.i3));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    double inside = 0.0;
+#pragma unroll
+                    for (int rr = q; rr < 8; ++rr)
+                        inside = (r == rr) ? p.l[tri8(rr, q)] : inside;
+                    At[(J0 + q) * kLdT + lane] = below ? x[q] : (above ? 0.0 : inside);
+                }
+                if (r >= 0 && r < kPw) {
+                    double iv = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)
+                        iv = (r == rr) ? p.inv[rr] : iv;
+                    invd[lane] = iv;
+                }
             }
         } else {
-            row[0] = x0; row[1] = x1; row[2] = x2; row[3] = x3;
             double* rr = R + lane * kLd + J0;
-            rr[0] = x0; rr[1] = x1; rr[2] = x2; rr[3] = x3;
-        }
-    }
-    RSTAMP(9);
-    __syncthreads();
-    RSTAMP(10);
-    // 3. rank-4 update of the tiles right of the pivot columns.  MFMA f64 maps: A[i = lane&15][k = lane>>4],
-    //    B[k = lane>>4][j = lane&15], C row = (lane>>4) + 4*reg, col = lane&15.
-    if (J0 + 4 < 64) {
-        constexpr int t0 = (J0 + 4) >> 4;
-        const int ra = 16 * w + fr;
-        const double adv = pd[ra * kPs + fk];
-        const double ad = (ra >= J0 + 4) ? -adv : 0.0;
-        const double at = HAS_T ? -pt[ra * kPs + fk] : 0.0;
-        // the tile that holds the next pivot columns goes first: the next round's publish waits on it
 #pragma unroll
-        for (int tj = t0; tj < 4; ++tj) {
-            const int rb = 16 * tj + fr;
-            const double bv = pd[rb * kPs + fk];
-            const double b = (rb >= J0 + 4) ? bv : 0.0;
-            // tiles above the diagonal (tj > w) get a zero operand instead of a branch: straight-line code
-            const double adm = (tj <= w) ? ad : 0.0;
-            Dacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(adm, b, Dacc[tj], 0, 0, 0);
-            if (HAS_T)
-                Tacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, b, Tacc[tj], 0, 0, 0);
+            for (int q = 0; q < 8; ++q) {
+                row[q] = x[q];
+                rr[q] = x[q];
+            }
         }
     }
-    RSTAMP(11);
+    __syncthreads();
+    // 3. rank-8 update of the tiles right of the pivot columns.  MFMA f64 maps: A[i = lane&15][k = lane>>4],
+    //    B[k = lane>>4][j = lane&15], C row = (lane>>4) + 4*reg, col = lane&15.
+    if (J0 + kPw < 64) {
+        constexpr int t0 = (J0 + kPw) >> 4;
+        const int ra = 16 * w + fr;
+        const bool ma = ra >= J0 + kPw;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const double adv = pd[ra * kPs + 4 * ks + fk];
+            const double ad = ma ? -adv : 0.0;
+            const double at = HAS_T ? -pt[ra * kPs + 4 * ks + fk] : 0.0;
+            // the tile that holds the next pivot columns goes first: the next round's publish waits on it
+#pragma unroll
+            for (int tj = t0; tj < 4; ++tj) {
+                const int rb = 16 * tj + fr;
+                const double bv = pd[rb * kPs + 4 * ks + fk];
+                const double b = (rb >= J0 + kPw) ? bv : 0.0;
+                // tiles above the diagonal (tj > w) get a zero operand instead of a branch
+                const double adm = (tj <= w) ? ad : 0.0;
+                Dacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(adm, b, Dacc[tj], 0, 0, 0);
+                if (HAS_T)
+                    Tacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, b, Tacc[tj], 0, 0, 0);
+            }
+        }
+    }
 }
 
 template <bool HAS_T>
 __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
                                            double* __restrict__ P, const double* __restrict__ Pprev,
-                                           double* __restrict__ dinv, double* RA, double* Pd, double* Pt,
-                                           double* invd, double* Ads, double* Ats)
+                                           double* __restrict__ dinv, double* __restrict__ Ld, double* RA,
+                                           double* Pd, double* Pt, double* invd, double* Ads, double* Ats)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -227,21 +291,13 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
     STAMP(1);
     bool ok = true;
     panel_round<0, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
-    panel_round<4, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     panel_round<8, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
-    panel_round<12, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     panel_round<16, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
-    panel_round<20, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     panel_round<24, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
-    panel_round<28, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     panel_round<32, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
-    panel_round<36, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     panel_round<40, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
-    panel_round<44, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     panel_round<48, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
-    panel_round<52, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     panel_round<56, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
-    panel_round<60, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok);
     __syncthreads();
     STAMP(2);
     if (!HAS_T) {
@@ -253,7 +309,7 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int r = idx >> 6, c = idx & 63;
             if (c <= r)
-                S[(int64_t)(K0 + r) * ld + K0 + c] = RA[c * kLdT + r];
+                Ld[(int64_t)k * 4096 + r * 64 + c] = RA[c * kLdT + r];
         }
         return;
     }
@@ -275,13 +331,13 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
     STAMP(5);
 }
 
-constexpr int kPanelSmem = 64 * kLdT + 4 * 64 * kPs + 64 + 2 * 64 * kLdsRow;   // doubles
+constexpr int kPanelSmem = 64 * kLdT + 4 * 64 * kPs + 64 + 2 * 64 * kLdsRow;   // doubles (kPs = 9: 4 x 576)
 constexpr int kUpdateSmem = 2 * 64 * kLdsRow;
 constexpr int kStepSmem = kPanelSmem > kUpdateSmem ? kPanelSmem : kUpdateSmem;
 
 __device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
                                               double* __restrict__ P, const double* __restrict__ Pprev,
-                                              double* __restrict__ dinv, double* smem)
+                                              double* __restrict__ dinv, double* __restrict__ Ld, double* smem)
 {
     double* RA = smem;                     // workgroup 0: L^T (stride kLdT); others: result tile R (stride kLd)
     double* Pd = RA + 64 * kLdT;
@@ -290,9 +346,9 @@ __device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S
     double* Ads = invd + 64;               // previous panel, diagonal rows (k-major); 16-byte aligned offsets
     double* Ats = Ads + 64 * kLdsRow;      // previous panel, this workgroup's rows
     if (blockIdx.x == 0)
-        panel_body<false>(ctl, S, ld, n_pad, k, P, Pprev, dinv, RA, Pd, Pt, invd, Ads, Ats);
+        panel_body<false>(ctl, S, ld, n_pad, k, P, Pprev, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
     else
-        panel_body<true>(ctl, S, ld, n_pad, k, P, Pprev, dinv, RA, Pd, Pt, invd, Ads, Ats);
+        panel_body<true>(ctl, S, ld, n_pad, k, P, Pprev, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
 }
 
 #ifdef VMM_STAMPS
@@ -382,7 +438,8 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
 // over the four waves), then workgroup kb solves its diagonal block four unknowns per round.
 __global__ __launch_bounds__(256) void k_backsolve_step(const LmCtl* ctl, double* __restrict__ S, int ld,
                                                         int n_pad, int n_blk, int kb, double* __restrict__ y,
-                                                        const double* __restrict__ dinv)
+                                                        const double* __restrict__ dinv,
+                                                        const double* __restrict__ Ld)
 {
     if (ctl->done || ctl->lin_fail)
         return;
@@ -409,7 +466,7 @@ __global__ __launch_bounds__(256) void k_backsolve_step(const LmCtl* ctl, double
         const int K0 = kb * kNB;
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int r = idx >> 6, cc = idx & 63;
-            L[r * kLd + cc] = (cc <= r) ? S[(int64_t)(K0 + r) * ld + K0 + cc] : 0.0;
+            L[r * kLd + cc] = (cc <= r) ? Ld[(int64_t)kb * 4096 + r * 64 + cc] : 0.0;
         }
         if (tid < 64)
             di[tid] = dinv[K0 + tid];
@@ -463,7 +520,7 @@ constexpr unsigned kSpinLimit = 1u << 22;
 __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const double* __restrict__ S, int ld,
                                                          int n_pad, int n_blk, double* y,
                                                          const double* __restrict__ dinv, unsigned* flags,
-                                                         unsigned* epoch_word)
+                                                         unsigned* epoch_word, const double* __restrict__ Ld)
 {
     if (ctl->done || ctl->lin_fail)
         return;
@@ -481,7 +538,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
         s_timeout = 0;
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int r = idx >> 6, cc = idx & 63;
-        L[r * kLd + cc] = (cc <= r) ? S[(int64_t)(K0 + r) * ld + K0 + cc] : 0.0;
+        L[r * kLd + cc] = (cc <= r) ? Ld[(int64_t)m * 4096 + r * 64 + cc] : 0.0;
     }
     if (tid < 64)
         di[tid] = dinv[K0 + tid];
@@ -563,13 +620,14 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
 // (throughput work) runs beside the latency-bound panel instead of in front of it.
 __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int n_blk,
                                                    int k, int n_panel, double* __restrict__ Pcur,
-                                                   const double* __restrict__ Pprev, double* __restrict__ dinv)
+                                                   const double* __restrict__ Pprev, double* __restrict__ dinv,
+                                                   double* __restrict__ Ld)
 {
     if (ctl->done || ctl->lin_fail)
         return;
     __shared__ __attribute__((aligned(16))) double smem[kStepSmem];
     if ((int)blockIdx.x < n_panel)
-        chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, dinv, smem);
+        chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, dinv, Ld, smem);
     else
         chol_update_wg(S, ld, n_blk, k - 1, (int)blockIdx.x - n_panel, Pprev, smem);
 }
@@ -591,16 +649,16 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         const int n_upd = k > 0 ? update_tiles(n_blk, k - 1) : 0;
         hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, k,
                            n_panel, e.P2[k & 1], k > 0 ? (const double*)e.P2[(k - 1) & 1] : (const double*)nullptr,
-                           e.dinv);
+                           e.dinv, e.Ldiag);
     }
     // one chained launch while every workgroup of the chain can be resident; the per-block kernels otherwise
     if (n_blk <= 200 && e.flags && !e.no_chain) {
         hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
-                           e.flags, e.flags + 256);
+                           e.flags, e.flags + 256, (const double*)e.Ldiag);
     } else {
         for (int kb = n_blk - 1; kb >= 0; --kb)
             hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y,
-                               e.dinv);
+                               e.dinv, (const double*)e.Ldiag);
     }
 }
 
