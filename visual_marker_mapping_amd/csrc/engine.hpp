@@ -14,7 +14,7 @@ namespace vmm {
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kPart = 32;          // doubles per task partial: 21 (H lower) + 6 (g) + 1 (cost) + pad
 constexpr int kNB = 64;            // dense block size of the reduced system
-constexpr int kKT = 32;            // K tile of the MFMA f64 SYRK
+constexpr int kKT = 32;            // K tile of the MFMA f64 rank-k update (rows of Z per LDS stage)
 constexpr int kLdsRow = 80;        // LDS row stride (doubles) for 64-wide tiles: rows k, k+1 land in
                                    // opposite 32-bank halves for ds_read_b64 (MI355X_MICROARCH LDS)
 
@@ -62,6 +62,13 @@ struct LmCtl {
     vmm_ba_iteration cur;      // record under construction
 };
 
+// Stream-K decomposition of the rank-k update (kernels_schur.hip): device arrays + sizes.
+struct SyrkPlan {
+    int n_tiles = 0, n_kt = 0, n_wg = 0, units_per_wg = 0, n_segments = 0;
+    int32_t *tile_bi = nullptr, *tile_bj = nullptr, *wg_seg0 = nullptr, *tile_seg0 = nullptr;
+    double* partials = nullptr;   // [n_segments][64*64]
+};
+
 struct Engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -104,9 +111,9 @@ struct Engine {
     double* Le = nullptr;           // [n_e][36] Cholesky factors of the damped E blocks
     double* ze = nullptr;           // [n_e][6]  L_e^{-1} g_e
     double* Z = nullptr;            // [k_pad][ldz] dense L_e^{-1} W (+ z column), row-major
-    int k_dim = 0, k_pad = 0, split_k = 1, k_chunk = 0;
+    int k_dim = 0, k_pad = 0;
     int n_red = 0, n_pad = 0, ldz = 0, n_blk = 0;   // reduced order, padded, leading dim, blocks
-    double* slabs = nullptr;        // [split_k][ldz*ldz]
+    SyrkPlan syrk;                  // stream-K plan of S = Z^T Z
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
     double* P = nullptr;            // [2][kNB][ldz] transposed Cholesky panels (alternating)
     double* P2[2] = { nullptr, nullptr };
@@ -153,11 +160,8 @@ void launch_elim(Engine& e);
 void launch_syrk_only(Engine& e);
 void launch_syrk_reduced(Engine& e);
 void launch_add_diag(Engine& e);
-void launch_syrk_raw(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, int row_blk0, int n_row_blk,
-                     int col_blk0, int n_col_blk, int split_k, int k_chunk, double* C, int ldc,
-                     size_t slab_stride, bool subtract);
-void launch_reduce_slabs(hipStream_t st, const LmCtl* ctl, const double* slabs, int split_k, size_t slab_stride,
-                         int ld, int n_rows, int n_cols, double* S);
+void launch_syrk_plan(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, const SyrkPlan& p);
+void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int ld, int n_rows, double* S);
 // kernels_chol.hip
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl);
 // kernels_lm.hip

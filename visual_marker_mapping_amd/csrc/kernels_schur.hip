@@ -8,7 +8,8 @@
 // (s = Jacobi column scaling, D^2 = LM diagonal / radius).
 // Z is stored dense, row-major [6 n_e (+pad)] x ldz with the rhs z as one extra column, so that
 // S and b come out of ONE symmetric rank-k update computed on the f64 matrix cores
-// (v_mfma_f64_16x16x4_f64), split along K into slabs that are summed in a fixed order.
+// (v_mfma_f64_16x16x4_f64); the (tile, K tile) work units are split evenly over the workgroups ("stream-K")
+// and the per-tile partial sums are added in a fixed order.
 #include "engine.hpp"
 
 namespace vmm {
@@ -136,163 +137,120 @@ __global__ __launch_bounds__(256) void k_form_z(const LmCtl* ctl, int64_t n_obs,
 
 // ---- symmetric rank-k update on the f64 matrix cores --------------------------------------------
 //
-// C(I,J) (+)= sum_k Z[k][I]^T Z[k][J] for 64x64 tiles with I >= J.  Workgroup = 4 waves, wave (wi,wj)
+// C(I,J) = sum_k Z[k][I]^T Z[k][J] for 64x64 tiles with I >= J.  Workgroup = 4 waves, wave (wi,wj)
 // owns a 32x32 quadrant = 2x2 MFMA 16x16 tiles.  v_mfma_f64_16x16x4_f64 operand maps (one f64 per
 // lane): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; result 4 f64 per lane at
 // col = lane&15, row = (lane>>4) + 4*reg (cdna_hip_programming.md, "f64 MFMA does NOT use these maps").
 // Both operands are rows of Z (k-major), so a lane reads 16 consecutive doubles of one Z row: the
 // tile is staged k-major in LDS with a row stride of 80 doubles so rows k and k+1 of a 32-lane
 // ds_read_b64 group fall into opposite bank halves.
+//
+// Work decomposition ("stream-K"): the unit of work is one K tile (32 rows of Z) of one output tile.
+// All units, ordered tile-major, are cut into equal contiguous ranges, one per workgroup, so every
+// workgroup issues the same number of MFMAs whatever the tile count (210 tiles on 512 workgroup slots
+// quantise badly with a fixed K split).  A workgroup writes one 64x64 partial per (tile) segment of its
+// range; k_reduce_partials sums a tile's partials in segment order -- deterministic, no atomics.
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-enum { SYRK_SLAB = 0, SYRK_SUB = 1 };
+constexpr int kSyrkKT = 32;
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_syrk(const LmCtl* ctl, const double* __restrict__ Z, int ldz,
-                                              int row_blk0, int n_row_blk, int col_blk0, int n_col_blk,
-                                              int k_chunk, double* __restrict__ C, int ldc,
-                                              size_t slab_stride)
+struct SyrkPlanDev {
+    int n_tiles, n_kt, n_wg, units_per_wg;
+    const int32_t* tile_bi;     // [n_tiles]
+    const int32_t* tile_bj;     // [n_tiles]
+    const int32_t* wg_seg0;     // [n_wg + 1] first segment id of each workgroup
+    const int32_t* tile_seg0;   // [n_tiles + 1] first segment id of each tile
+    double* partials;           // [n_segments][64*64]
+};
+
+__global__ __launch_bounds__(256) void k_syrk_streamk(const LmCtl* ctl, const double* __restrict__ Z, int ldz,
+                                                      SyrkPlanDev pl)
 {
     if (ctl && ctl->done)
         return;
-    // blockIdx.x enumerates lower-triangular tiles (bi >= bj) of the requested block range,
-    // blockIdx.y the K split.
-    int t = blockIdx.x;
-    int bi = 0, bj = 0;
-    {
-        // tile list: for each row block r (absolute index), columns col_blk0 .. min(r, col_end-1)
-        const int col_end = col_blk0 + n_col_blk;
-        bool found = false;
-        for (int r = row_blk0; r < row_blk0 + n_row_blk; ++r) {
-            const int last = (r < col_end - 1) ? r : col_end - 1;
-            const int cnt = last - col_blk0 + 1;
-            if (cnt <= 0)
-                continue;
-            if (t < cnt) {
-                bi = r;
-                bj = col_blk0 + t;
-                found = true;
-                break;
-            }
-            t -= cnt;
-        }
-        if (!found)
-            return;  // uniform per workgroup: the host sizes the grid to the exact tile count
-    }
-    const int k0 = blockIdx.y * k_chunk;
-    const int I0 = bi * kNB, J0 = bj * kNB;
-    const bool diag = (bi == bj);
-
-    // K tiles of 32 rows, double-buffered in LDS; the next tile's global loads are issued before the
-    // current tile's 32 MFMAs per wave so that the memory latency hides behind the wave's own compute.
-    constexpr int KT = 32;
-    __shared__ __attribute__((aligned(16))) double As[2][KT * kLdsRow];
-    __shared__ __attribute__((aligned(16))) double Bs[2][KT * kLdsRow];
-
+    __shared__ __attribute__((aligned(16))) double As[2][kSyrkKT * kLdsRow];
+    __shared__ __attribute__((aligned(16))) double Bs[2][kSyrkKT * kLdsRow];
+    const int g = blockIdx.x;
+    const int64_t units = (int64_t)pl.n_tiles * pl.n_kt;
+    int64_t u = (int64_t)g * pl.units_per_wg;
+    const int64_t u_end = (u + pl.units_per_wg < units) ? u + pl.units_per_wg : units;
+    int seg = pl.wg_seg0[g];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    // global->LDS: 32 rows x 64 cols = 2048 doubles per operand, 256 threads x 2 x double4
-    const int lr = tid >> 4;          // 0..15 (+16 for the second half)
+    const int lr = tid >> 4;          // 0..15 (+16 for the second half of a K tile)
     const int lc = (tid & 15) * 4;    // 0..60
-    double4_t acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-            acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-
     const int fk = lane >> 4, fi = lane & 15;
-    const int n_kt = k_chunk / KT;      // host guarantees k_chunk % 32 == 0
-    double4_t va[2], vb[2];
-    auto gload = [&](int kt) {
+    while (u < u_end) {
+        const int t = (int)(u / pl.n_kt);
+        const int kt0 = (int)(u % pl.n_kt);
+        const int64_t left = u_end - u;
+        const int kt1 = (kt0 + left < pl.n_kt) ? (int)(kt0 + left) : pl.n_kt;
+        const int I0 = pl.tile_bi[t] * kNB, J0 = pl.tile_bj[t] * kNB;
+        const bool diag = I0 == J0;
+        double4_t acc[2][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const double* zr = Z + (int64_t)(k0 + kt * KT + lr + 16 * h) * ldz;
-            va[h] = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
-            vb[h] = diag ? va[h] : *reinterpret_cast<const double4_t*>(zr + J0 + lc);
-        }
-    };
-    auto lstore = [&](int buf) {
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<double4_t*>(&As[buf][(lr + 16 * h) * kLdsRow + lc]) = va[h];
-            if (!diag)
-                *reinterpret_cast<double4_t*>(&Bs[buf][(lr + 16 * h) * kLdsRow + lc]) = vb[h];
-        }
-    };
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < n_kt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < n_kt)
-            gload(kt + 1);
-        const double* Ap = As[buf];
-        const double* Bp = diag ? As[buf] : Bs[buf];
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+        double4_t va[2], vb[2];
+        auto gload = [&](int kt) {
 #pragma unroll
-        for (int ks = 0; ks < KT / 4; ++ks) {
-            const int row = (ks * 4 + fk) * kLdsRow;
-            const double a0 = Ap[row + wi * 32 + fi];
-            const double a1 = Ap[row + wi * 32 + 16 + fi];
-            const double b0 = Bp[row + wj * 32 + fi];
-            const double b1 = Bp[row + wj * 32 + 16 + fi];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < n_kt)
-            lstore(buf ^ 1);
-        __syncthreads();
-    }
-    double* Cb = C + (MODE == SYRK_SLAB ? (size_t)blockIdx.y * slab_stride : 0);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = I0 + wi * 32 + a * 16 + fk + 4 * r;
-                const int col = J0 + wj * 32 + b * 16 + fi;
-                double* p = Cb + (int64_t)row * ldc + col;
-                if (MODE == SYRK_SLAB)
-                    *p = acc[a][b][r];
-                else
-                    *p -= acc[a][b][r];
+            for (int h = 0; h < 2; ++h) {
+                const double* zr = Z + (int64_t)(kt * kSyrkKT + lr + 16 * h) * ldz;
+                va[h] = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
+                vb[h] = diag ? va[h] : *reinterpret_cast<const double4_t*>(zr + J0 + lc);
             }
-}
-
-// number of lower tiles with row block in [row_blk0, row_blk0+n_row_blk) and column block in
-// [col_blk0, col_blk0+n_col_blk), bj <= bi
-static int count_tiles(int row_blk0, int n_row_blk, int col_blk0, int n_col_blk)
-{
-    int n = 0;
-    for (int r = row_blk0; r < row_blk0 + n_row_blk; ++r) {
-        const int last = (r < col_blk0 + n_col_blk - 1) ? r : col_blk0 + n_col_blk - 1;
-        if (last >= col_blk0)
-            n += last - col_blk0 + 1;
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<double4_t*>(&As[buf][(lr + 16 * h) * kLdsRow + lc]) = va[h];
+                if (!diag)
+                    *reinterpret_cast<double4_t*>(&Bs[buf][(lr + 16 * h) * kLdsRow + lc]) = vb[h];
+            }
+        };
+        gload(kt0);
+        __syncthreads();   // the previous segment's last tile is fully consumed
+        lstore(0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1)
+                gload(kt + 1);   // next tile's loads fly while this tile's 32 MFMAs per wave issue
+            const double* Ap = As[buf];
+            const double* Bp = diag ? As[buf] : Bs[buf];
+#pragma unroll
+            for (int ks = 0; ks < kSyrkKT / 4; ++ks) {
+                const int row = (ks * 4 + fk) * kLdsRow;
+                const double a0 = Ap[row + wi * 32 + fi];
+                const double a1 = Ap[row + wi * 32 + 16 + fi];
+                const double b0 = Bp[row + wj * 32 + fi];
+                const double b1 = Bp[row + wj * 32 + 16 + fi];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (kt + 1 < kt1)
+                lstore(buf ^ 1);
+            __syncthreads();
+        }
+        double* Cb = pl.partials + (size_t)seg * 4096;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cb[(wi * 32 + a * 16 + fk + 4 * r) * 64 + wj * 32 + b * 16 + fi] = acc[a][b][r];
+        u += kt1 - kt0;
+        ++seg;
     }
-    return n;
 }
 
-void launch_syrk_raw(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, int row_blk0, int n_row_blk,
-                     int col_blk0, int n_col_blk, int split_k, int k_chunk, double* C, int ldc,
-                     size_t slab_stride, bool subtract)
-{
-    const int tiles = count_tiles(row_blk0, n_row_blk, col_blk0, n_col_blk);
-    if (tiles <= 0)
-        return;
-    if (subtract)
-        hipLaunchKernelGGL((k_syrk<SYRK_SUB>), dim3(tiles, 1), dim3(256), 0, st, ctl, Z, ldz, row_blk0,
-                           n_row_blk, col_blk0, n_col_blk, k_chunk, C, ldc, slab_stride);
-    else
-        hipLaunchKernelGGL((k_syrk<SYRK_SLAB>), dim3(tiles, split_k), dim3(256), 0, st, ctl, Z, ldz, row_blk0,
-                           n_row_blk, col_blk0, n_col_blk, k_chunk, C, ldc, slab_stride);
-}
-
-// S = -(sum of slabs) over the lower block triangle (row blocks 0..n_blk incl. the rhs row block).
 struct DiagArgs {        // kept family's damped diagonal blocks and rhs, added in the same pass on one GPU
     const double* H_F;
     const double* g_F;
@@ -301,42 +259,45 @@ struct DiagArgs {        // kept family's damped diagonal blocks and rhs, added 
     int n_red, n_pad;
 };
 
+// S(tile) = -(sum of the tile's partials, in segment order) [+ damped diagonal blocks / rhs / padding].
+// One workgroup per tile, 16 elements per thread.
 template <bool ADD_DIAG>
-__global__ __launch_bounds__(256) void k_reduce_slabs(const LmCtl* ctl, const double* __restrict__ slabs,
-                                                      int split_k, size_t slab_stride, int ld, int n_rows,
-                                                      int n_cols, double* __restrict__ S, DiagArgs da)
+__global__ __launch_bounds__(256) void k_reduce_partials(const LmCtl* ctl, SyrkPlanDev pl, int ld, int n_rows,
+                                                         double* __restrict__ S, DiagArgs da)
 {
     if (ctl && ctl->done)
         return;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = (int)(idx / n_cols), col = (int)(idx % n_cols);
-    if (row >= n_rows)
-        return;
-    if ((col / kNB) > (row / kNB))
-        return;
-    const int64_t off = (int64_t)row * ld + col;
-    double s = 0.0;
-    for (int k = 0; k < split_k; ++k)
-        s += slabs[(size_t)k * slab_stride + off];
-    double v = -s;
-    if (ADD_DIAG) {
-        if (row == da.n_pad) {                       // rhs row: b = s_f g_f - Z^T z
-            if (col < da.n_red)
-                v += da.scale_F[col] * da.g_F[col];
-        } else if (row < da.n_red && col <= row && (row / 6) == (col / 6)) {
-            const int f = row / 6, a = row % 6, b = col % 6;
-            v += da.scale_F[row] * da.H_F[36 * (int64_t)f + 6 * a + b] * da.scale_F[col];
-            if (a == b)
-                v += da.D2_F[row];
-        } else if (row >= da.n_red && row < da.n_pad && col == row) {
-            v = 1.0;                                 // padding of the reduced system
+    const int t = blockIdx.x;
+    const int I0 = pl.tile_bi[t] * kNB, J0 = pl.tile_bj[t] * kNB;
+    const int s0 = pl.tile_seg0[t], s1 = pl.tile_seg0[t + 1];
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        const int row = I0 + r, col = J0 + c;
+        if (row >= n_rows)
+            continue;
+        double s = 0.0;
+        for (int q = s0; q < s1; ++q)
+            s += pl.partials[(size_t)q * 4096 + e];
+        double v = -s;
+        if (ADD_DIAG) {
+            if (row == da.n_pad) {                       // rhs row: b = s_f g_f - Z^T z
+                if (col < da.n_red)
+                    v += da.scale_F[col] * da.g_F[col];
+            } else if (row < da.n_red && col <= row && (row / 6) == (col / 6)) {
+                const int f = row / 6, a = row % 6, b = col % 6;
+                v += da.scale_F[row] * da.H_F[36 * (int64_t)f + 6 * a + b] * da.scale_F[col];
+                if (a == b)
+                    v += da.D2_F[row];
+            } else if (row >= da.n_red && row < da.n_pad && col == row) {
+                v = 1.0;                                 // padding of the reduced system
+            }
         }
+        S[(int64_t)row * ld + col] = v;
     }
-    S[off] = v;
 }
 
-// Adds the kept family's damped diagonal blocks and right-hand side (identical on every rank, so it
-// runs after the all-reduce): S_ff += s H_f s + D_f^2, padded diagonal = 1, rhs row += s_f g_f.
+// Adds the kept family's damped diagonal blocks and right-hand side (identical on every rank, so with
+// world > 1 it runs after the all-reduce): S_ff += s H_f s + D_f^2, padded diagonal = 1, rhs row += s_f g_f.
 __global__ void k_add_diag(const LmCtl* ctl, int n_f, int f_off_pose, const double* __restrict__ H_F,
                            const double* __restrict__ g_F, const double* __restrict__ scale,
                            const double* __restrict__ D2, double* __restrict__ S, int ld, int n_red,
@@ -365,6 +326,21 @@ __global__ void k_add_diag(const LmCtl* ctl, int n_f, int f_off_pose, const doub
 
 // ---- launchers -----------------------------------------------------------------------------------
 
+static SyrkPlanDev plan_dev(const SyrkPlan& p)
+{
+    SyrkPlanDev d;
+    d.n_tiles = p.n_tiles;
+    d.n_kt = p.n_kt;
+    d.n_wg = p.n_wg;
+    d.units_per_wg = p.units_per_wg;
+    d.tile_bi = p.tile_bi;
+    d.tile_bj = p.tile_bj;
+    d.wg_seg0 = p.wg_seg0;
+    d.tile_seg0 = p.tile_seg0;
+    d.partials = p.partials;
+    return d;
+}
+
 void launch_elim(Engine& e)
 {
     const int e_off = e.elim_cams ? 0 : e.n_cams;
@@ -379,30 +355,29 @@ void launch_elim(Engine& e)
                            e.Z, e.ldz);
 }
 
-void launch_reduce_slabs(hipStream_t st, const LmCtl* ctl, const double* slabs, int split_k, size_t slab_stride,
-                         int ld, int n_rows, int n_cols, double* S)
+void launch_syrk_plan(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, const SyrkPlan& p)
 {
-    const int64_t total = (int64_t)n_rows * n_cols;
+    if (p.n_wg > 0)
+        hipLaunchKernelGGL(k_syrk_streamk, dim3(p.n_wg), dim3(256), 0, st, ctl, Z, ldz, plan_dev(p));
+}
+
+void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int ld, int n_rows, double* S)
+{
     DiagArgs da = {};
-    hipLaunchKernelGGL((k_reduce_slabs<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctl, slabs,
-                       split_k, slab_stride, ld, n_rows, n_cols, S, da);
+    if (p.n_tiles > 0)
+        hipLaunchKernelGGL((k_reduce_partials<false>), dim3(p.n_tiles), dim3(256), 0, st, ctl, plan_dev(p), ld, n_rows,
+                           S, da);
 }
 
-// slabs[s] = (Z^T Z)(K chunk s): row blocks 0..n_blk (the last one holds the rhs row), column blocks 0..n_blk-1
-void launch_syrk_only(Engine& e)
-{
-    launch_syrk_raw(e.stream, e.ctl, e.Z, e.ldz, 0, e.n_blk + 1, 0, e.n_blk, e.split_k, e.k_chunk, e.slabs,
-                    e.ldz, (size_t)e.ldz * e.ldz, false);
-}
+void launch_syrk_only(Engine& e) { launch_syrk_plan(e.stream, e.ctl, e.Z, e.ldz, e.syrk); }
 
-// S = -(sum of slabs) [+ damped diagonal blocks and rhs on one GPU; with world > 1 they are added by
+// S = -(sum of partials) [+ damped diagonal blocks and rhs on one GPU; with world > 1 they are added by
 // launch_add_diag after the all-reduce, being identical on every rank]
 void launch_syrk_reduced(Engine& e)
 {
     launch_syrk_only(e);
     if (e.multi) {
-        launch_reduce_slabs(e.stream, e.ctl, e.slabs, e.split_k, (size_t)e.ldz * e.ldz, e.ldz, e.n_pad + 1, e.n_pad,
-                            e.S);
+        launch_reduce_plan(e.stream, e.ctl, e.syrk, e.ldz, e.n_pad + 1, e.S);
         return;
     }
     const int f_off = e.elim_cams ? e.n_cams : 0;
@@ -413,9 +388,8 @@ void launch_syrk_reduced(Engine& e)
     da.D2_F = e.D2 + 6 * (size_t)f_off;
     da.n_red = e.n_red;
     da.n_pad = e.n_pad;
-    const int64_t total = (int64_t)(e.n_pad + 1) * e.n_pad;
-    hipLaunchKernelGGL((k_reduce_slabs<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, e.stream, e.ctl,
-                       e.slabs, e.split_k, (size_t)e.ldz * e.ldz, e.ldz, e.n_pad + 1, e.n_pad, e.S, da);
+    hipLaunchKernelGGL((k_reduce_partials<true>), dim3(e.syrk.n_tiles), dim3(256), 0, e.stream, e.ctl,
+                       plan_dev(e.syrk), e.ldz, e.n_pad + 1, e.S, da);
 }
 
 void launch_add_diag(Engine& e)

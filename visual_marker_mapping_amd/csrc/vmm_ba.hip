@@ -108,6 +108,66 @@ static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx
     return VMM_BA_OK;
 }
 
+// Stream-K plan: lower 64x64 tiles with row blocks 0..n_row_blk-1 and column blocks 0..n_col_blk-1
+// (bj <= bi), K tiles of 32 rows; all (tile, K tile) units are cut into equal contiguous ranges.
+static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, int k_pad)
+{
+    std::vector<int32_t> bi, bj;
+    for (int r = 0; r < n_row_blk; ++r)
+        for (int c = 0; c <= std::min(r, n_col_blk - 1); ++c) {
+            bi.push_back(r);
+            bj.push_back(c);
+        }
+    p.n_tiles = (int)bi.size();
+    p.n_kt = k_pad / kKT;
+    const int64_t units = (int64_t)p.n_tiles * p.n_kt;
+    // two workgroups (80 KB of LDS each) per CU; for larger problems whole multiples of that keep the tail short
+    int hw = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e.device) == hipSuccess)
+        hw = prop.multiProcessorCount;
+    if (hw <= 0)
+        hw = 256;
+    const int64_t slots = 2 * (int64_t)hw;
+    int64_t n_wg = std::min<int64_t>(units, slots);
+    if (units > 64 * slots)
+        n_wg = 4 * slots;   // plenty of K tiles per workgroup: several waves of workgroups balance the chip
+    p.units_per_wg = (int)((units + n_wg - 1) / std::max<int64_t>(n_wg, 1));
+    p.n_wg = p.units_per_wg > 0 ? (int)((units + p.units_per_wg - 1) / p.units_per_wg) : 0;
+    std::vector<int32_t> wg_seg0((size_t)p.n_wg + 1, 0), tile_seg0((size_t)p.n_tiles + 1, 0);
+    // segments in unit order: cut at tile boundaries and at workgroup boundaries
+    int seg = 0;
+    for (int g = 0; g < p.n_wg; ++g) {
+        wg_seg0[g] = seg;
+        int64_t u = (int64_t)g * p.units_per_wg;
+        const int64_t u_end = std::min<int64_t>(units, u + p.units_per_wg);
+        while (u < u_end) {
+            const int t = (int)(u / p.n_kt);
+            const int kt0 = (int)(u % p.n_kt);
+            const int64_t take = std::min<int64_t>(p.n_kt - kt0, u_end - u);
+            if (kt0 == 0)
+                tile_seg0[t] = seg;
+            u += take;
+            ++seg;
+        }
+    }
+    wg_seg0[p.n_wg] = seg;
+    tile_seg0[p.n_tiles] = seg;
+    p.n_segments = seg;
+    int rc;
+    if ((rc = dev_alloc(e, &p.tile_bi, bi.size()))) return rc;
+    if ((rc = dev_alloc(e, &p.tile_bj, bj.size()))) return rc;
+    if ((rc = dev_alloc(e, &p.wg_seg0, wg_seg0.size()))) return rc;
+    if ((rc = dev_alloc(e, &p.tile_seg0, tile_seg0.size()))) return rc;
+    if ((rc = dev_alloc(e, &p.partials, (size_t)std::max(seg, 1) * 4096, false))) return rc;
+    if ((rc = upload(e, p.tile_bi, bi))) return rc;
+    if ((rc = upload(e, p.tile_bj, bj))) return rc;
+    if ((rc = upload(e, p.wg_seg0, wg_seg0))) return rc;
+    if ((rc = upload(e, p.tile_seg0, tile_seg0))) return rc;
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    return VMM_BA_OK;
+}
+
 // the two alternating transposed-panel buffers of the look-ahead Cholesky; P must be allocated
 static int setup_lookahead(Engine& e, int n_blk_max, int ld)
 {
@@ -419,20 +479,12 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.n_blk = e.n_pad / kNB;
     e.ldz = e.n_pad + kNB;
     e.k_dim = 6 * e.n_e;
-    {
-        const int tiles = e.n_blk * (e.n_blk + 1) / 2 + e.n_blk;
-        int split = (1024 + tiles - 1) / tiles;
-        split = std::max(1, std::min(split, 16));
-        const int max_split = std::max(1, e.k_dim / 64);
-        split = std::min(split, max_split);
-        e.split_k = split;
-        e.k_chunk = round_up((e.k_dim + split - 1) / split, kKT);
-        e.k_pad = e.k_chunk * split;
-    }
+    e.k_pad = round_up(e.k_dim, kKT);
     if ((rc = dev_alloc(e, &e.Le, (size_t)36 * e.n_e))) return fail(rc);
     if ((rc = dev_alloc(e, &e.ze, (size_t)6 * e.n_e))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Z, (size_t)e.k_pad * e.ldz))) return fail(rc);
-    if ((rc = dev_alloc(e, &e.slabs, (size_t)e.split_k * e.ldz * e.ldz))) return fail(rc);
+    // row blocks 0..n_blk (the last one holds the rhs row), column blocks 0..n_blk-1
+    if ((rc = make_syrk_plan(e, e.syrk, e.n_blk + 1, e.n_blk, e.k_pad))) return fail(rc);
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * e.ldz))) return fail(rc);
     if ((rc = setup_lookahead(e, e.n_blk, e.ldz))) return fail(rc);
@@ -818,15 +870,14 @@ int vmm_ba_dense_syrk(int device, int k, int n, const double* Zh, double* C)
     }
     const int n_pad = round_up(n, kNB), ld = n_pad;
     const int n_blk = n_pad / kNB;
-    const int split = (k >= 64) ? 2 : 1;
-    const int k_chunk = round_up((k + split - 1) / split, kKT);
-    const int k_pad = k_chunk * split;
+    const int k_pad = round_up(k, kKT);
     Engine e;
     int rc = make_scratch(e, device, ld);
-    double *Z = nullptr, *slabs = nullptr, *S = nullptr;
+    double *Z = nullptr, *S = nullptr;
+    SyrkPlan plan;
     if (!rc) rc = dev_alloc(e, &Z, (size_t)k_pad * ld);
-    if (!rc) rc = dev_alloc(e, &slabs, (size_t)split * ld * ld);
     if (!rc) rc = dev_alloc(e, &S, (size_t)ld * ld);
+    if (!rc) rc = make_syrk_plan(e, plan, n_blk, n_blk, k_pad);
     if (rc) {
         free_scratch(e);
         return rc;
@@ -838,8 +889,8 @@ int vmm_ba_dense_syrk(int device, int k, int n, const double* Zh, double* C)
     hipError_t err = hipMemcpyAsync(Z, hz.data(), sizeof(double) * hz.size(), hipMemcpyHostToDevice, e.stream);
     std::vector<double> hs((size_t)ld * ld, 0.0);
     if (err == hipSuccess) {
-        launch_syrk_raw(e.stream, nullptr, Z, ld, 0, n_blk, 0, n_blk, split, k_chunk, slabs, ld, (size_t)ld * ld, false);
-        launch_reduce_slabs(e.stream, nullptr, slabs, split, (size_t)ld * ld, ld, n_pad, n_pad, S);
+        launch_syrk_plan(e.stream, nullptr, Z, ld, plan);
+        launch_reduce_plan(e.stream, nullptr, plan, ld, n_pad, S);
         err = hipGetLastError();
     }
     if (err == hipSuccess) err = hipMemcpyAsync(hs.data(), S, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, e.stream);
