@@ -38,15 +38,8 @@ struct EvalArgs {
 __device__ __forceinline__ int tri(int a, int b) { return a * (a + 1) / 2 + b; }
 
 template <bool OWN_IS_CAM, bool WRITE_W>
-__global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
+__device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
 {
-    if (a.ctl) {
-        if (a.ctl->done)
-            return;
-        if (a.guard_need_jacobian && !a.ctl->need_jacobian)
-            return;
-    }
-    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (wave >= a.n_tasks)
         return;
@@ -151,11 +144,46 @@ __global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
         a.part[(int64_t)wave * kPart + lane] = mine;
 }
 
+template <bool OWN_IS_CAM, bool WRITE_W>
+__global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
+{
+    if (a.ctl) {
+        if (a.ctl->done)
+            return;
+        if (a.guard_need_jacobian && !a.ctl->need_jacobian)
+            return;
+    }
+    eval_body<OWN_IS_CAM, WRITE_W>(a, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+}
+
+// Both family passes in one launch: workgroups [0, nb_e) run the pass over the eliminated family (writes W),
+// the rest the pass over the kept family.  The passes are independent, so they share the chip.
+template <bool E_IS_CAM>
+__global__ __launch_bounds__(256) void k_eval_both(const EvalArgs aE, const EvalArgs aF, const int nb_e)
+{
+    if (aE.ctl) {
+        if (aE.ctl->done)
+            return;
+        if (aE.guard_need_jacobian && !aE.ctl->need_jacobian)
+            return;
+    }
+    if ((int)blockIdx.x < nb_e)
+        eval_body<E_IS_CAM, true>(aE, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    else
+        eval_body<!E_IS_CAM, false>(aF, (int)(((blockIdx.x - nb_e) * blockDim.x + threadIdx.x) >> 6));
+}
+
 // Sums the task partials of every pose in task order and expands the packed lower triangle.
-__global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, int n_pose,
-                              const int32_t* __restrict__ pose_task, const double* __restrict__ part,
-                              double* __restrict__ Hout, double* __restrict__ gout,
-                              double* __restrict__ pose_cost)
+struct ReduceArgs {
+    int n_pose;
+    const int32_t* pose_task;
+    const double* part;
+    double* Hout;
+    double* gout;
+    double* pose_cost;   // or null
+};
+
+__global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, const ReduceArgs rE, const ReduceArgs rF)
 {
     if (ctl) {
         if (ctl->done)
@@ -163,7 +191,17 @@ __global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, int n_p
         if (guard_need_jacobian && !ctl->need_jacobian)
             return;
     }
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool first = tid < 32 * rE.n_pose;
+    if (!first)
+        tid -= 32 * rE.n_pose;
+    const ReduceArgs& r = first ? rE : rF;
+    const int n_pose = r.n_pose;
+    const int32_t* __restrict__ pose_task = r.pose_task;
+    const double* __restrict__ part = r.part;
+    double* __restrict__ Hout = r.Hout;
+    double* __restrict__ gout = r.gout;
+    double* __restrict__ pose_cost = r.pose_cost;
     const int p = tid >> 5, k = tid & 31;
     if (p >= n_pose || k >= 28)
         return;
@@ -395,18 +433,36 @@ void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, do
 void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bool use_ctl)
 {
     const bool e_is_cam = e.elim_cams;
-    launch_eval_pass(e, true, guard, robustify, huber_a, use_ctl);
-    launch_eval_pass(e, false, guard, robustify, huber_a, use_ctl);
+    EvalArgs aE = make_eval_args(e, e.ordE, e_is_cam, e.W, guard);
+    EvalArgs aF = make_eval_args(e, e.ordF, !e_is_cam, nullptr, guard);
+    aE.robustify = aF.robustify = robustify;
+    aE.huber_a = aF.huber_a = huber_a;
+    if (!use_ctl)
+        aE.ctl = aF.ctl = nullptr;
+    const int nb_e = blocks_for_tasks(aE.n_tasks), nb_f = blocks_for_tasks(aF.n_tasks);
+    if (nb_e + nb_f > 0) {
+        if (e_is_cam)
+            hipLaunchKernelGGL((k_eval_both<true>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
+        else
+            hipLaunchKernelGGL((k_eval_both<false>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
+    }
     const LmCtl* ctl = use_ctl ? e.ctl : nullptr;
-    double* H_E = e_is_cam ? e.ev_H_cam : e.ev_H_tag;
-    double* g_E = e_is_cam ? e.ev_g_cam : e.ev_g_tag;
-    double* H_F = e_is_cam ? e.ev_H_tag : e.ev_H_cam;
-    double* g_F = e_is_cam ? e.ev_g_tag : e.ev_g_cam;
     const int gguard = guard ? 1 : 0;
-    hipLaunchKernelGGL(k_reduce_pose, dim3((e.n_e * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
-                       e.n_e, e.ordE.pose_task, e.ordE.part, H_E, g_E, e.part_cost /* per-pose cost */);
-    hipLaunchKernelGGL(k_reduce_pose, dim3((e.n_f * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
-                       e.n_f, e.ordF.pose_task, e.ordF.part, H_F, g_F, (double*)nullptr);
+    ReduceArgs rE, rF;
+    rE.n_pose = e.n_e;
+    rE.pose_task = e.ordE.pose_task;
+    rE.part = e.ordE.part;
+    rE.Hout = e_is_cam ? e.ev_H_cam : e.ev_H_tag;
+    rE.gout = e_is_cam ? e.ev_g_cam : e.ev_g_tag;
+    rE.pose_cost = e.part_cost;   // per-pose cost of the eliminated family
+    rF.n_pose = e.n_f;
+    rF.pose_task = e.ordF.pose_task;
+    rF.part = e.ordF.part;
+    rF.Hout = e_is_cam ? e.ev_H_tag : e.ev_H_cam;
+    rF.gout = e_is_cam ? e.ev_g_tag : e.ev_g_cam;
+    rF.pose_cost = nullptr;
+    hipLaunchKernelGGL(k_reduce_pose, dim3(((e.n_e + e.n_f) * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
+                       rE, rF);
     if (e.multi || !use_ctl)   // single-GPU solves sum the pose costs in k_iter_begin
         hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1, e.ev_cost);
 }

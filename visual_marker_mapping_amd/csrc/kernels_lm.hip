@@ -39,6 +39,37 @@ __device__ __forceinline__ double block_max(double v, double* sh)
     return r;
 }
 
+// Sums (and maxes) several per-thread values over a 256-thread block with ONE barrier: wave butterflies,
+// then wave 0's lanes combine the four wave totals.  v[0..NS) are summed, v[NS..NS+NM) are maxed; every
+// thread returns with the block totals in v.  Fixed order -> deterministic.
+template <int NS, int NM>
+__device__ __forceinline__ void block_reduce_multi(double (&v)[NS + NM], double* sh /* [4][NS+NM] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+        v[k] = wave_sum(v[k]);
+#pragma unroll
+    for (int k = NS; k < NS + NM; ++k) {
+#pragma unroll
+        for (int mk = 32; mk >= 1; mk >>= 1)
+            v[k] = fmax(v[k], __shfl_xor(v[k], mk, 64));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NS + NM; ++k)
+            sh[wave * (NS + NM) + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+        v[k] = (sh[k] + sh[(NS + NM) + k]) + (sh[2 * (NS + NM) + k] + sh[3 * (NS + NM) + k]);
+#pragma unroll
+    for (int k = NS; k < NS + NM; ++k)
+        v[k] = fmax(fmax(sh[k], sh[(NS + NM) + k]), fmax(sh[2 * (NS + NM) + k], sh[3 * (NS + NM) + k]));
+    __syncthreads();
+}
+
 struct PoseViews {
     int n_cams, n_tags;
     double* cam_qt;
@@ -116,12 +147,11 @@ __global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, co
         if (pose_cost)
             for (int i = tid; i < n_pose_cost; i += 256)
                 cst += pose_cost[i];
-        xn = block_sum(xn, sh);
-        gm = block_max(gm, sh);
-        cst = pose_cost ? block_sum(cst, sh) : cost_slot[0];
-        s_xn = xn;
-        s_gm = gm;
-        s_cst = cst;
+        double red[3] = { xn, cst, gm };
+        block_reduce_multi<2, 1>(red, sh);
+        s_xn = red[0];
+        s_gm = red[2];
+        s_cst = pose_cost ? red[1] : cost_slot[0];
         s_evaluated = 1;
     }
     __syncthreads();
@@ -401,13 +431,15 @@ __global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const 
     if (cost_parts)
         for (int i = tid; i < n_cost; i += 256)
             ccost += cost_parts[i];
-    gd = block_sum(gd, sh);
-    quad = block_sum(quad, sh);
-    sn = block_sum(sn, sh);
-    xn = block_sum(xn, sh);
-    bad = block_max(bad, sh);
-    cross = cross_parts ? block_sum(cross, sh) : cross_slot[0];
-    ccost = cost_parts ? block_sum(ccost, sh) : cand_cost_slot[0];
+    double red[7] = { gd, quad, sn, xn, cross, ccost, bad };
+    block_reduce_multi<6, 1>(red, sh);
+    gd = red[0];
+    quad = red[1];
+    sn = red[2];
+    xn = red[3];
+    cross = cross_parts ? red[4] : cross_slot[0];
+    ccost = cost_parts ? red[5] : cand_cost_slot[0];
+    bad = red[6];
     if (tid == 0) {
         // one load and one store of the control block (see k_iter_begin)
         LmCtl c = *ctl;

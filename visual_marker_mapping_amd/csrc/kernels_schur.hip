@@ -270,15 +270,25 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const LmCtl* ctl, SyrkP
     const int t = blockIdx.x;
     const int I0 = pl.tile_bi[t] * kNB, J0 = pl.tile_bj[t] * kNB;
     const int s0 = pl.tile_seg0[t], s1 = pl.tile_seg0[t + 1];
-    for (int e = threadIdx.x; e < 4096; e += 256) {
+    // 16 elements per thread, all loads of a segment in flight together
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        acc[i] = 0.0;
+    for (int q = s0; q < s1; ++q) {
+        const double* pq = pl.partials + (size_t)q * 4096 + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc[i] += pq[256 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = threadIdx.x + 256 * i;
         const int r = e >> 6, c = e & 63;
         const int row = I0 + r, col = J0 + c;
         if (row >= n_rows)
             continue;
-        double s = 0.0;
-        for (int q = s0; q < s1; ++q)
-            s += pl.partials[(size_t)q * 4096 + e];
-        double v = -s;
+        double v = -acc[i];
         if (ADD_DIAG) {
             if (row == da.n_pad) {                       // rhs row: b = s_f g_f - Z^T z
                 if (col < da.n_red)
