@@ -119,6 +119,7 @@ struct Engine {
     double* P2[2] = { nullptr, nullptr };
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
     double* Ldiag = nullptr;        // [n_blk][64][64] Cholesky factors of the diagonal blocks
+    double* Linv = nullptr;         // [n_blk][64][64] their inverses (all but the last block)
     unsigned* flags = nullptr;      // [256] hand-off flags of the chained back-substitution + [1] epoch word
     bool no_chain = false;          // VMM_BA_NO_CHAIN=1: per-block back-substitution kernels
     double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)

@@ -520,7 +520,8 @@ constexpr unsigned kSpinLimit = 1u << 22;
 __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const double* __restrict__ S, int ld,
                                                          int n_pad, int n_blk, double* y,
                                                          const double* __restrict__ dinv, unsigned* flags,
-                                                         unsigned* epoch_word, const double* __restrict__ Ld)
+                                                         unsigned* epoch_word, const double* __restrict__ Ld,
+                                                         const double* __restrict__ Linv)
 {
     if (ctl->done || ctl->lin_fail)
         return;
@@ -536,12 +537,22 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     const int K0 = m * kNB;
     if (tid == 0)
         s_timeout = 0;
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int r = idx >> 6, cc = idx & 63;
-        L[r * kLd + cc] = (cc <= r) ? Ld[(int64_t)m * 4096 + r * 64 + cc] : 0.0;
+    double li[16];   // my 16 rows of column c of Linv_mm (requested now, used after the last hand-off)
+    if (m < n_blk - 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            li[r] = Linv[(int64_t)m * 4096 + (part * 16 + r) * 64 + c];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            li[r] = 0.0;
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int r = idx >> 6, cc = idx & 63;
+            L[r * kLd + cc] = (cc <= r) ? Ld[(int64_t)m * 4096 + r * 64 + cc] : 0.0;
+        }
+        if (tid < 64)
+            di[tid] = dinv[K0 + tid];
     }
-    if (tid < 64)
-        di[tid] = dinv[K0 + tid];
     double acc = 0.0;
     double lt[16], ln[16];
     int j = n_blk - 1;
@@ -583,23 +594,40 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     if (part == 0)
         wc = S[(int64_t)n_pad * ld + K0 + c] - ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
     double yv = 0.0;
-    for (int j0 = 60; j0 >= 0; j0 -= 4) {
+    if (m < n_blk - 1) {
+        // y_m = Linv^T t : the inverse of this block was computed beside a later panel; 64x64 GEMV
         if (part == 0)
             ws[c] = wc;
         __syncthreads();
-        if (part == 0) {
-            const double* D = L + j0 * kLd + j0;
-            const double v3 = ws[j0 + 3] * di[j0 + 3];
-            const double v2 = (ws[j0 + 2] - D[3 * kLd + 2] * v3) * di[j0 + 2];
-            const double v1 = (ws[j0 + 1] - D[2 * kLd + 1] * v2 - D[3 * kLd + 1] * v3) * di[j0 + 1];
-            const double v0 = (ws[j0] - D[kLd] * v1 - D[2 * kLd] * v2 - D[3 * kLd] * v3) * di[j0];
-            if (c >= j0 && c < j0 + 4)
-                yv = (c == j0) ? v0 : (c == j0 + 1 ? v1 : (c == j0 + 2 ? v2 : v3));
-            if (c < j0)
-                wc -= L[j0 * kLd + c] * v0 + L[(j0 + 1) * kLd + c] * v1 + L[(j0 + 2) * kLd + c] * v2
-                    + L[(j0 + 3) * kLd + c] * v3;
-        }
+        double a2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            a2 += li[r] * ws[part * 16 + r];
+        __syncthreads();   // everyone has read red[] above and ws
+        red[part][c] = a2;
         __syncthreads();
+        if (part == 0)
+            yv = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    } else {
+        // last block (first in the chain): its inverse is not available, solve four unknowns per round
+        for (int j0 = 60; j0 >= 0; j0 -= 4) {
+            if (part == 0)
+                ws[c] = wc;
+            __syncthreads();
+            if (part == 0) {
+                const double* D = L + j0 * kLd + j0;
+                const double v3 = ws[j0 + 3] * di[j0 + 3];
+                const double v2 = (ws[j0 + 2] - D[3 * kLd + 2] * v3) * di[j0 + 2];
+                const double v1 = (ws[j0 + 1] - D[2 * kLd + 1] * v2 - D[3 * kLd + 1] * v3) * di[j0 + 1];
+                const double v0 = (ws[j0] - D[kLd] * v1 - D[2 * kLd] * v2 - D[3 * kLd] * v3) * di[j0];
+                if (c >= j0 && c < j0 + 4)
+                    yv = (c == j0) ? v0 : (c == j0 + 1 ? v1 : (c == j0 + 2 ? v2 : v3));
+                if (c < j0)
+                    wc -= L[j0 * kLd + c] * v0 + L[(j0 + 1) * kLd + c] * v1 + L[(j0 + 2) * kLd + c] * v2
+                        + L[(j0 + 3) * kLd + c] * v3;
+            }
+            __syncthreads();
+        }
     }
     if (part == 0) {
         __hip_atomic_store(&y[K0 + c], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -614,6 +642,46 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     }
 }
 
+// Explicit inverse of one 64x64 lower-triangular diagonal factor (for the chained back-substitution,
+// which then needs a 64x64 GEMV per block instead of 16 dependent 4x4 solves).  One wave, thread c
+// solves L x = e_c; entries above row c are zero, so all lanes run the same 2016 multiply-adds.
+// Runs as one extra workgroup of a later launch, beside the latency-bound panel: free.
+__device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, const double* __restrict__ dinvk,
+                                                double* __restrict__ Linvk, double* smem)
+{
+    double* L = smem;
+    double* di = smem + 64 * kLd;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        L[r * kLd + c] = (c <= r) ? Ldk[idx] : 0.0;
+    }
+    if (tid < 64)
+        di[tid] = dinvk[tid];
+    __syncthreads();
+    if (tid >= 64)
+        return;
+    const int c = tid;
+    double x[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int m = 0; m + 3 < i; m += 4) {
+            s0 += L[i * kLd + m] * x[m];
+            s1 += L[i * kLd + m + 1] * x[m + 1];
+            s2 += L[i * kLd + m + 2] * x[m + 2];
+            s3 += L[i * kLd + m + 3] * x[m + 3];
+        }
+#pragma unroll
+        for (int m = (i / 4) * 4; m < i; ++m)
+            s0 += L[i * kLd + m] * x[m];
+        const double s = (s0 + s1) + (s2 + s3);
+        x[i] = (i == c) ? di[i] : ((i < c) ? 0.0 : -s * di[i]);
+        Linvk[i * 64 + c] = x[i];
+    }
+}
+
 // One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their
 // own column from panel k-1), the others apply the trailing update of panel k-1 to the columns >= k+1.
 // The two parts touch disjoint tiles and both only need results of the previous launch, so the update
@@ -621,15 +689,17 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
 __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int n_blk,
                                                    int k, int n_panel, double* __restrict__ Pcur,
                                                    const double* __restrict__ Pprev, double* __restrict__ dinv,
-                                                   double* __restrict__ Ld)
+                                                   double* __restrict__ Ld, double* __restrict__ Linv, int n_upd)
 {
     if (ctl->done || ctl->lin_fail)
         return;
     __shared__ __attribute__((aligned(16))) double smem[kStepSmem];
     if ((int)blockIdx.x < n_panel)
         chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, dinv, Ld, smem);
-    else
+    else if ((int)blockIdx.x < n_panel + n_upd)
         chol_update_wg(S, ld, n_blk, k - 1, (int)blockIdx.x - n_panel, Pprev, smem);
+    else   // last workgroup of launches k >= 1: invert the diagonal factor of block k-1
+        chol_inverse_wg(Ld + (int64_t)(k - 1) * 4096, dinv + (k - 1) * kNB, Linv + (int64_t)(k - 1) * 4096, smem);
 }
 
 static int update_tiles(int n_blk, int k)   // tiles of the trailing update of panel k: columns >= k+2
@@ -647,14 +717,15 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
         const int n_panel = 1 + (rows_below + 63) / 64;
         const int n_upd = k > 0 ? update_tiles(n_blk, k - 1) : 0;
-        hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, k,
-                           n_panel, e.P2[k & 1], k > 0 ? (const double*)e.P2[(k - 1) & 1] : (const double*)nullptr,
-                           e.dinv, e.Ldiag);
+        hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd + (k > 0 ? 1 : 0)), dim3(256), 0, e.stream, ctl, S, ld,
+                           n_pad, n_blk, k, n_panel, e.P2[k & 1],
+                           k > 0 ? (const double*)e.P2[(k - 1) & 1] : (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
+                           n_upd);
     }
     // one chained launch while every workgroup of the chain can be resident; the per-block kernels otherwise
     if (n_blk <= 200 && e.flags && !e.no_chain) {
         hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
-                           e.flags, e.flags + 256, (const double*)e.Ldiag);
+                           e.flags, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
     } else {
         for (int kb = n_blk - 1; kb >= 0; --kb)
             hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y,

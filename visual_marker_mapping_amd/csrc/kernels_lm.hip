@@ -250,14 +250,17 @@ __global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, co
     }
 }
 
-// Back-substitution of the eliminated family: y_e = L_e^{-T} (z_e - Z_e y_f), delta_e = -s_e y_e.
-// One wave per eliminated pose.
-__global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose,
+// Back-substitution of the eliminated family: y_e = L_e^{-T} (z_e - Z_e y_f), delta_e = -s_e y_e, and
+// the pose's share of the model-cost cross term sum_obs delta_e^T W_ef delta_f.  One wave per
+// eliminated pose (its observations are contiguous in E order).
+__global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose, int f_off_pose,
                                                  const int32_t* __restrict__ pose_task,
+                                                 const Task* __restrict__ tasks, const int32_t* __restrict__ other,
+                                                 const double* __restrict__ W, int64_t n_pad_obs,
                                                  const double* __restrict__ Z, int ldz, int n_red,
                                                  const double* __restrict__ yf, const double* __restrict__ Le,
                                                  const double* __restrict__ ze, const double* __restrict__ scale,
-                                                 double* __restrict__ step_comm)
+                                                 double* __restrict__ step_comm, double* __restrict__ part_cross)
 {
     if (ctl->done)
         return;
@@ -265,10 +268,13 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
     const int lane = threadIdx.x & 63;
     if (e >= n_e)
         return;
-    const bool owned = pose_task[e + 1] > pose_task[e];
+    const int t0 = pose_task[e], t1 = pose_task[e + 1];
+    const bool owned = t1 > t0;
     if (!owned || ctl->lin_fail) {
         if (lane < 6)
             step_comm[6 * (int64_t)e + lane] = 0.0;
+        if (lane == 0)
+            part_cross[e] = 0.0;
         return;
     }
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
@@ -292,51 +298,41 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
             s -= L[6 * k + i] * v[k];
         v[i] = s / L[6 * i + i];
     }
+    double de[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        de[i] = -v[i] * scale[6 * (int64_t)(e_off_pose + e) + i];
     if (lane < 6) {
         double out = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-            out = (lane == i) ? v[i] : out;
-        step_comm[6 * (int64_t)e + lane] = -out * scale[6 * (int64_t)(e_off_pose + e) + lane];
+            out = (lane == i) ? de[i] : out;
+        step_comm[6 * (int64_t)e + lane] = out;
     }
-}
-
-// Cross term of the model cost: per observation delta_e^T W_ef delta_f (E order), wave partials.
-__global__ __launch_bounds__(256) void k_cross(const LmCtl* ctl, const Task* __restrict__ tasks, int n_tasks,
-                                               const int32_t* __restrict__ other, const double* __restrict__ W,
-                                               int64_t n_pad, const double* __restrict__ step_comm,
-                                               const double* __restrict__ yf, const double* __restrict__ scale,
-                                               int f_off_pose, double* __restrict__ part)
-{
-    if (ctl->done)
-        return;
-    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
-    if (wave >= n_tasks)
-        return;
-    const Task t = tasks[wave];
-    const int64_t i = (int64_t)t.begin + lane;
-    double v = 0.0;
-    if (i < t.end && !ctl->lin_fail) {
-        const int f = other[i];
-        double de[6], df[6];
+    // cross term over this pose's observations
+    double cr = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const Task tk = tasks[t];
+        const int64_t i = (int64_t)tk.begin + lane;
+        if (i < tk.end) {
+            const int f = other[i];
+            double df[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            de[k] = step_comm[6 * (int64_t)t.pose + k];
-            df[k] = -yf[6 * f + k] * scale[6 * (int64_t)(f_off_pose + f) + k];
-        }
+            for (int k = 0; k < 6; ++k)
+                df[k] = -yf[6 * f + k] * scale[6 * (int64_t)(f_off_pose + f) + k];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            double r = 0.0;
+            for (int a = 0; a < 6; ++a) {
+                double r = 0.0;
 #pragma unroll
-            for (int b = 0; b < 6; ++b)
-                r += W[(int64_t)(6 * a + b) * n_pad + i] * df[b];
-            v += de[a] * r;
+                for (int b = 0; b < 6; ++b)
+                    r += W[(int64_t)(6 * a + b) * n_pad_obs + i] * df[b];
+                cr += de[a] * r;
+            }
         }
     }
-    v = wave_sum(v);
+    cr = wave_sum(cr);
     if (lane == 0)
-        part[wave] = v;
+        part_cross[e] = cr;
 }
 
 // delta (unscaled tangent step) for every pose, the candidate x+ = Plus(x, delta)
@@ -561,12 +557,9 @@ void launch_backsub(Engine& e)
 {
     const int e_off = e.elim_cams ? 0 : e.n_cams;
     const int f_off = e.elim_cams ? e.n_cams : 0;
-    hipLaunchKernelGGL(k_backsub, dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
-                       e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm);
-    if (e.ordE.n_tasks > 0)
-        hipLaunchKernelGGL(k_cross, dim3((e.ordE.n_tasks + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.ordE.tasks,
-                           e.ordE.n_tasks, e.ordE.other, e.W, e.ordE.n_pad, e.step_comm, e.yf, e.scale, f_off,
-                           e.part_cross);
+    hipLaunchKernelGGL(k_backsub, dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, f_off,
+                       e.ordE.pose_task, e.ordE.tasks, e.ordE.other, e.W, e.ordE.n_pad, e.Z, e.ldz, e.n_red, e.yf,
+                       e.Le, e.ze, e.scale, e.step_comm, e.part_cross);
 }
 
 void launch_candidate(Engine& e)
@@ -582,7 +575,7 @@ void launch_decide(Engine& e)
 {
     const bool single = !e.multi;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), e.pose_part,
-                       e.step_comm + 6 * (size_t)e.n_e, single ? e.part_cross : (const double*)nullptr, e.ordE.n_tasks,
+                       e.step_comm + 6 * (size_t)e.n_e, single ? e.part_cross : (const double*)nullptr, e.n_e,
                        e.cost_comm, single ? e.part_k1 : (const double*)nullptr, e.ordE.n_tasks);
 }
 

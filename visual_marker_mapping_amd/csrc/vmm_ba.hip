@@ -227,7 +227,7 @@ static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
     launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
     launch_backsub(e);
     if (e.multi) {
-        launch_sum(e, true, e.part_cross, e.ordE.n_tasks, e.step_comm + 6 * (size_t)e.n_e);
+        launch_sum(e, true, e.part_cross, e.n_e, e.step_comm + 6 * (size_t)e.n_e);
         if ((rc = do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1))) return rc;
     }
     launch_candidate(e);
@@ -490,6 +490,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = setup_lookahead(e, e.n_blk, e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.Linv, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
     if ((rc = dev_alloc(e, &e.flags, 260))) return fail(rc);
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.step_comm, (size_t)6 * e.n_e + 2))) return fail(rc);
@@ -800,6 +801,7 @@ static int make_scratch(Engine& e, int device, int ld)
     if ((rc = setup_lookahead(e, ld / kNB, ld))) return rc;
     if ((rc = dev_alloc(e, &e.dinv, (size_t)ld + kNB))) return rc;
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(ld / kNB + 1) * 4096))) return rc;
+    if ((rc = dev_alloc(e, &e.Linv, (size_t)(ld / kNB + 1) * 4096))) return rc;
     if ((rc = dev_alloc(e, &e.flags, 260))) return rc;
     { const char* nc = getenv("VMM_BA_NO_CHAIN"); e.no_chain = nc && nc[0] == '1'; }
     if ((rc = dev_alloc(e, &e.ctl, 1))) return rc;
