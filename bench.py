@@ -178,12 +178,12 @@ def main():
             nb = (n_red + 63) // 64
             traffic = {"eval_jacobian": bpl.get("eval_jacobian"), "eval_cost": bpl.get("eval_cost"),
                        "schur_syrk": bpl.get("schur_syrk"),
-                       "cholesky_solve": nb * bpl.get("chol_panel", 0) + (nb - 1) * bpl.get("chol_update", 0)
-                       + nb * bpl.get("backsolve_step", 0)}
+                       "cholesky_solve": nb * bpl.get("chol_step", 0) + bpl.get("backsolve_chain", 0)}
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
-        names = {"cholesky_solve": "cholesky_solve = k_chol_panel + k_chol_update + k_backsolve_step (%d launches)"
-                                   % (3 * ((n_red + 63) // 64) - 1)}
+        names = {"cholesky_solve": "cholesky_solve = %d x k_chol_step (panel k fused with the trailing update of "
+                                   "panel k-1) + k_backsolve_chain" % ((n_red + 63) // 64),
+                 "schur_syrk": "k_syrk_streamk", "eval_jacobian": "k_eval_both", "eval_cost": "k_cost"}
         line["roofline"] = {"kernel": names.get(dom, dom), "bound": d["bound"], "achieved": d["achieved"],
                             "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": traffic.get(dom),
                             "avg_launch_ms": d["ms"]}

@@ -31,13 +31,14 @@ def traffic(names):
 
 
 groups = {
-    "eval_jacobian": ["k_eval<true, true>", "k_eval<false, false>"],
+    "eval_jacobian": ["k_eval_both<true>"],
     "eval_cost": ["k_cost<true>"],
-    "schur_syrk": ["k_syrk<0>"],
+    "schur_syrk": ["k_syrk_streamk"],
+    "syrk_reduce": ["k_reduce_partials<true>"],
     "form_z": ["k_form_z"],
-    "chol_panel": ["k_chol_panel"],
-    "chol_update": ["k_chol_update"],
-    "backsolve_step": ["k_backsolve_step"],
+    "chol_step": ["k_chol_step"],
+    "backsolve_chain": ["k_backsolve_chain"],
+    "backsub": ["k_backsub"],
 }
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 14 --warmup 7`, "
                  "500x200; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950 correction)",

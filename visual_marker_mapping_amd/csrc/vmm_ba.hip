@@ -956,18 +956,28 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     hipEvent_t ev0, ev1;
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
+    // each timed piece is captured into a hipGraph once and replayed, so that the gaps between its
+    // launches are the ones the production iteration graph sees
     auto timed = [&](auto&& fn, auto&& prep, double* ms_out) -> int {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIP_TRY(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+        fn();
+        HIP_TRY(hipStreamEndCapture(e.stream, &g));
+        HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
         double total = 0.0;
-        for (int r = 0; r < reps; ++r) {
+        for (int r = 0; r < reps + 1; ++r) {   // replay 0 is untimed
             prep();
             HIP_TRY(hipEventRecord(ev0, e.stream));
-            fn();
+            HIP_TRY(hipGraphLaunch(ge, e.stream));
             HIP_TRY(hipEventRecord(ev1, e.stream));
             HIP_TRY(hipEventSynchronize(ev1));
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-            total += ms;
+            if (r > 0) total += ms;
         }
+        (void)hipGraphExecDestroy(ge);
         *ms_out = total / reps;
         return VMM_BA_OK;
     };
