@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvmm_ba.so")
+# VMM_BA_LIB selects another build of the same ABI (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("VMM_BA_LIB") or os.path.join(_HERE, "libvmm_ba.so")
 
 OK, ERR_ARGUMENT, ERR_HIP, ERR_COLLECTIVE, ERR_STATE = 0, 1, 2, 3, 4
 ELIM_AUTO, ELIM_TAGS, ELIM_CAMERAS = 0, 1, 2

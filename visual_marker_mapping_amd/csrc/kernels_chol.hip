@@ -381,7 +381,6 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
         t -= cnt;
     }
     const int I0 = bi * kNB, J0 = bj * kNB;
-    const bool diag = bi == bj;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
@@ -392,7 +391,7 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
         const int idx = it * 256 + tid;
         const int m = idx >> 5, c = (idx & 31) * 2;
         va[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + I0 + c);
-        vb[it] = diag ? va[it] : *reinterpret_cast<const double2*>(P + (int64_t)m * ld + J0 + c);
+        vb[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + J0 + c);   // diagonal tile: same lines again
     }
     double4_t acc[2][2];
 #pragma unroll
@@ -407,11 +406,10 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
         const int idx = it * 256 + tid;
         const int m = idx >> 5, c = (idx & 31) * 2;
         *reinterpret_cast<double2*>(&As[m * kLdsRow + c]) = va[it];
-        if (!diag)
-            *reinterpret_cast<double2*>(&Bs[m * kLdsRow + c]) = vb[it];
+        *reinterpret_cast<double2*>(&Bs[m * kLdsRow + c]) = vb[it];
     }
     __syncthreads();
-    const double* Bp = diag ? As : Bs;
+    const double* Bp = Bs;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         const int row = (ks * 4 + fk) * kLdsRow;
