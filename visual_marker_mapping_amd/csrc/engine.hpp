@@ -14,7 +14,8 @@ namespace vmm {
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kPart = 32;          // doubles per task partial: 21 (H lower) + 6 (g) + 1 (cost) + pad
 constexpr int kNB = 64;            // dense block size of the reduced system
-constexpr int kKT = 32;            // K tile of the MFMA f64 rank-k update (rows of Z per LDS stage)
+constexpr int kKT = 16;            // K tile of the MFMA f64 rank-k update (rows of Z per LDS stage)
+constexpr int kST = 128;           // output tile of the rank-k update (the leading dimension is a multiple of it)
 constexpr int kLdsRow = 80;        // LDS row stride (doubles) for 64-wide tiles: rows k, k+1 land in
                                    // opposite 32-bank halves for ds_read_b64 (MI355X_MICROARCH LDS)
 
@@ -66,7 +67,7 @@ struct LmCtl {
 struct SyrkPlan {
     int n_tiles = 0, n_kt = 0, n_wg = 0, units_per_wg = 0, n_segments = 0;
     int32_t *tile_bi = nullptr, *tile_bj = nullptr, *wg_seg0 = nullptr, *tile_seg0 = nullptr;
-    double* partials = nullptr;   // [n_segments][64*64]
+    double* partials = nullptr;   // [n_segments][kST*kST]
 };
 
 struct Engine {

@@ -137,40 +137,48 @@ __global__ __launch_bounds__(256) void k_form_z(const LmCtl* ctl, int64_t n_obs,
 
 // ---- symmetric rank-k update on the f64 matrix cores --------------------------------------------
 //
-// C(I,J) = sum_k Z[k][I]^T Z[k][J] for 64x64 tiles with I >= J.  Workgroup = 4 waves, wave (wi,wj)
-// owns a 32x32 quadrant = 2x2 MFMA 16x16 tiles.  v_mfma_f64_16x16x4_f64 operand maps (one f64 per
-// lane): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; result 4 f64 per lane at
-// col = lane&15, row = (lane>>4) + 4*reg (cdna_hip_programming.md, "f64 MFMA does NOT use these maps").
-// Both operands are rows of Z (k-major), so a lane reads 16 consecutive doubles of one Z row: the
-// tile is staged k-major in LDS with a row stride of 80 doubles so rows k and k+1 of a 32-lane
-// ds_read_b64 group fall into opposite bank halves.
+// C(I,J) = sum_k Z[k][I]^T Z[k][J] for 128x128 tiles with I >= J.  Workgroup = 4 waves, wave (wi,wj)
+// owns a 64x64 quadrant = 4x4 MFMA 16x16 tiles (64 accumulator registers per lane).
+// v_mfma_f64_16x16x4_f64 operand maps (one f64 per lane): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15]; result 4 f64 per lane at col = lane&15, row = (lane>>4) + 4*reg
+// (cdna_hip_programming.md, "f64 MFMA does NOT use these maps").  Both operands are rows of Z (k-major),
+// so a lane reads 16 consecutive doubles of one Z row: the tile is staged k-major in LDS with a row
+// stride of 144 doubles so rows k and k+1 of a 32-lane ds_read_b64 group fall into opposite bank halves.
 //
-// Work decomposition ("stream-K"): the unit of work is one K tile (32 rows of Z) of one output tile.
+// Tile size: Z is far larger than an XCD's L2 and every workgroup streams its own two operand panels,
+// so the kernel's HBM traffic is (tiles) x K x (rows + columns of a tile) x 8 B.  With 64x64 tiles that
+// was 575 MB per launch at 500x200 (PMC FETCH_SIZE; 5.2 TB/s over the 111 us launch -- bandwidth-bound
+// at 8 flop/B); 128x128 tiles double the intensity to 16 flop/B and halve the traffic.
+//
+// Work decomposition ("stream-K"): the unit of work is one K tile (16 rows of Z) of one output tile.
 // All units, ordered tile-major, are cut into equal contiguous ranges, one per workgroup, so every
-// workgroup issues the same number of MFMAs whatever the tile count (210 tiles on 512 workgroup slots
-// quantise badly with a fixed K split).  A workgroup writes one 64x64 partial per (tile) segment of its
-// range; k_reduce_partials sums a tile's partials in segment order -- deterministic, no atomics.
+// workgroup issues the same number of MFMAs whatever the tile count (55 tiles on 256 CUs quantise badly
+// with a fixed K split).  A workgroup writes one 128x128 partial per (tile) segment of its range;
+// k_reduce_partials sums a tile's partials in segment order -- deterministic, no atomics.
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kSyrkKT = 32;
+constexpr int kSyrkKT = kKT;        // 16 rows of Z per LDS stage
+constexpr int kSyrkT = kST;         // 128x128 output tiles
+constexpr int kSyrkRow = 144;       // LDS row stride (doubles) of a 128-wide stage
+constexpr int kSyrkTile = kSyrkT * kSyrkT;
 
 struct SyrkPlanDev {
     int n_tiles, n_kt, n_wg, units_per_wg;
-    const int32_t* tile_bi;     // [n_tiles]
+    const int32_t* tile_bi;     // [n_tiles] in units of 128 rows
     const int32_t* tile_bj;     // [n_tiles]
     const int32_t* wg_seg0;     // [n_wg + 1] first segment id of each workgroup
     const int32_t* tile_seg0;   // [n_tiles + 1] first segment id of each tile
-    double* partials;           // [n_segments][64*64]
+    double* partials;           // [n_segments][128*128]
 };
 
-__global__ __launch_bounds__(256) void k_syrk_streamk(const LmCtl* ctl, const double* __restrict__ Z, int ldz,
-                                                      SyrkPlanDev pl)
+__global__ __launch_bounds__(256, 2) void k_syrk_streamk(const LmCtl* ctl, const double* __restrict__ Z, int ldz,
+                                                         SyrkPlanDev pl)
 {
     if (ctl && ctl->done)
         return;
-    __shared__ __attribute__((aligned(16))) double As[2][kSyrkKT * kLdsRow];
-    __shared__ __attribute__((aligned(16))) double Bs[2][kSyrkKT * kLdsRow];
+    __shared__ __attribute__((aligned(16))) double As[2][kSyrkKT * kSyrkRow];
+    __shared__ __attribute__((aligned(16))) double Bs[2][kSyrkKT * kSyrkRow];
     const int g = blockIdx.x;
     const int64_t units = (int64_t)pl.n_tiles * pl.n_kt;
     int64_t u = (int64_t)g * pl.units_per_wg;
@@ -179,73 +187,81 @@ __global__ __launch_bounds__(256) void k_syrk_streamk(const LmCtl* ctl, const do
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
-    const int lr = tid >> 4;          // 0..15 (+16 for the second half of a K tile)
-    const int lc = (tid & 15) * 4;    // 0..60
+    const int lr = tid >> 5;          // 0..7 (+8 for the second half of a K tile)
+    const int lc = (tid & 31) * 4;    // 0..124
     const int fk = lane >> 4, fi = lane & 15;
     while (u < u_end) {
         const int t = (int)(u / pl.n_kt);
         const int kt0 = (int)(u % pl.n_kt);
         const int64_t left = u_end - u;
         const int kt1 = (kt0 + left < pl.n_kt) ? (int)(kt0 + left) : pl.n_kt;
-        const int I0 = pl.tile_bi[t] * kNB, J0 = pl.tile_bj[t] * kNB;
+        const int I0 = pl.tile_bi[t] * kSyrkT, J0 = pl.tile_bj[t] * kSyrkT;
         const bool diag = I0 == J0;
-        double4_t acc[2][2];
+        double4_t acc[4][4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 4; ++b)
                 acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
         double4_t va[2], vb[2];
         auto gload = [&](int kt) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const double* zr = Z + (int64_t)(kt * kSyrkKT + lr + 16 * h) * ldz;
+                const double* zr = Z + (int64_t)(kt * kSyrkKT + lr + 8 * h) * ldz;
                 va[h] = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
-                vb[h] = diag ? va[h] : *reinterpret_cast<const double4_t*>(zr + J0 + lc);
+                vb[h] = *reinterpret_cast<const double4_t*>(zr + J0 + lc);   // diagonal tile: the same lines
             }
         };
         auto lstore = [&](int buf) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                *reinterpret_cast<double4_t*>(&As[buf][(lr + 16 * h) * kLdsRow + lc]) = va[h];
-                if (!diag)
-                    *reinterpret_cast<double4_t*>(&Bs[buf][(lr + 16 * h) * kLdsRow + lc]) = vb[h];
+                *reinterpret_cast<double4_t*>(&As[buf][(lr + 8 * h) * kSyrkRow + lc]) = va[h];
+                *reinterpret_cast<double4_t*>(&Bs[buf][(lr + 8 * h) * kSyrkRow + lc]) = vb[h];
             }
         };
         gload(kt0);
-        __syncthreads();   // the previous segment's last tile is fully consumed
+        __syncthreads();   // the previous segment's last stage is fully consumed
         lstore(0);
         __syncthreads();
+        // the strictly upper 64x64 quadrant of a diagonal tile is never read: its wave only keeps the barriers
+        const bool live = !(diag && wi == 0 && wj == 1);
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
             if (kt + 1 < kt1)
-                gload(kt + 1);   // next tile's loads fly while this tile's 32 MFMAs per wave issue
+                gload(kt + 1);   // next stage's loads fly while this stage's 64 MFMAs per wave issue
             const double* Ap = As[buf];
-            const double* Bp = diag ? As[buf] : Bs[buf];
+            const double* Bp = Bs[buf];
+            if (live) {
 #pragma unroll
-            for (int ks = 0; ks < kSyrkKT / 4; ++ks) {
-                const int row = (ks * 4 + fk) * kLdsRow;
-                const double a0 = Ap[row + wi * 32 + fi];
-                const double a1 = Ap[row + wi * 32 + 16 + fi];
-                const double b0 = Bp[row + wj * 32 + fi];
-                const double b1 = Bp[row + wj * 32 + 16 + fi];
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                for (int ks = 0; ks < kSyrkKT / 4; ++ks) {
+                    const int row = (ks * 4 + fk) * kSyrkRow;
+                    double a[4], b[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] = Ap[row + wi * 64 + 16 * i + fi];
+                        b[i] = Bp[row + wj * 64 + 16 * i + fi];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
             }
             if (kt + 1 < kt1)
                 lstore(buf ^ 1);
             __syncthreads();
         }
-        double* Cb = pl.partials + (size_t)seg * 4096;
+        double* Cb = pl.partials + (size_t)seg * kSyrkTile;
+        if (live) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Cb[(wi * 32 + a * 16 + fk + 4 * r) * 64 + wj * 32 + b * 16 + fi] = acc[a][b][r];
+                    for (int r = 0; r < 4; ++r)
+                        Cb[(wi * 64 + a * 16 + fk + 4 * r) * kSyrkT + wj * 64 + b * 16 + fi] = acc[a][b][r];
+        }
         u += kt1 - kt0;
         ++seg;
     }
@@ -260,32 +276,35 @@ struct DiagArgs {        // kept family's damped diagonal blocks and rhs, added 
 };
 
 // S(tile) = -(sum of the tile's partials, in segment order) [+ damped diagonal blocks / rhs / padding].
-// One workgroup per tile, 16 elements per thread.
+// Four workgroups per 128x128 tile (one per 64x64 quadrant; the strictly upper quadrant of a diagonal
+// tile is skipped), 16 elements per thread.
 template <bool ADD_DIAG>
 __global__ __launch_bounds__(256) void k_reduce_partials(const LmCtl* ctl, SyrkPlanDev pl, int ld, int n_rows,
                                                          double* __restrict__ S, DiagArgs da)
 {
     if (ctl && ctl->done)
         return;
-    const int t = blockIdx.x;
-    const int I0 = pl.tile_bi[t] * kNB, J0 = pl.tile_bj[t] * kNB;
+    const int t = blockIdx.x >> 2;
+    const int qi = (blockIdx.x >> 1) & 1, qj = blockIdx.x & 1;
+    const int I0 = pl.tile_bi[t] * kSyrkT + 64 * qi, J0 = pl.tile_bj[t] * kSyrkT + 64 * qj;
+    if (J0 > I0 || I0 >= n_rows)
+        return;
     const int s0 = pl.tile_seg0[t], s1 = pl.tile_seg0[t + 1];
+    const int tr = threadIdx.x >> 6, tc = threadIdx.x & 63;   // element (tr + 4 i, tc) of the quadrant
     // 16 elements per thread, all loads of a segment in flight together
     double acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
         acc[i] = 0.0;
     for (int q = s0; q < s1; ++q) {
-        const double* pq = pl.partials + (size_t)q * 4096 + threadIdx.x;
+        const double* pq = pl.partials + (size_t)q * kSyrkTile + (64 * qi + tr) * kSyrkT + 64 * qj + tc;
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            acc[i] += pq[256 * i];
+            acc[i] += pq[4 * i * kSyrkT];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int e = threadIdx.x + 256 * i;
-        const int r = e >> 6, c = e & 63;
-        const int row = I0 + r, col = J0 + c;
+        const int row = I0 + tr + 4 * i, col = J0 + tc;
         if (row >= n_rows)
             continue;
         double v = -acc[i];
@@ -375,7 +394,7 @@ void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int
 {
     DiagArgs da = {};
     if (p.n_tiles > 0)
-        hipLaunchKernelGGL((k_reduce_partials<false>), dim3(p.n_tiles), dim3(256), 0, st, ctl, plan_dev(p), ld, n_rows,
+        hipLaunchKernelGGL((k_reduce_partials<false>), dim3(4 * p.n_tiles), dim3(256), 0, st, ctl, plan_dev(p), ld, n_rows,
                            S, da);
 }
 
@@ -398,7 +417,7 @@ void launch_syrk_reduced(Engine& e)
     da.D2_F = e.D2 + 6 * (size_t)f_off;
     da.n_red = e.n_red;
     da.n_pad = e.n_pad;
-    hipLaunchKernelGGL((k_reduce_partials<true>), dim3(e.syrk.n_tiles), dim3(256), 0, e.stream, e.ctl,
+    hipLaunchKernelGGL((k_reduce_partials<true>), dim3(4 * e.syrk.n_tiles), dim3(256), 0, e.stream, e.ctl,
                        plan_dev(e.syrk), e.ldz, e.n_pad + 1, e.S, da);
 }
 

@@ -108,8 +108,8 @@ static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx
     return VMM_BA_OK;
 }
 
-// Stream-K plan: lower 64x64 tiles with row blocks 0..n_row_blk-1 and column blocks 0..n_col_blk-1
-// (bj <= bi), K tiles of 32 rows; all (tile, K tile) units are cut into equal contiguous ranges.
+// Stream-K plan: lower 128x128 tiles with row blocks 0..n_row_blk-1 and column blocks 0..n_col_blk-1
+// (bj <= bi), K tiles of 16 rows; all (tile, K tile) units are cut into equal contiguous ranges.
 static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, int k_pad)
 {
     std::vector<int32_t> bi, bj;
@@ -121,14 +121,17 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
     p.n_tiles = (int)bi.size();
     p.n_kt = k_pad / kKT;
     const int64_t units = (int64_t)p.n_tiles * p.n_kt;
-    // two workgroups (80 KB of LDS each) per CU; for larger problems whole multiples of that keep the tail short
+    // two workgroups (72 KB of LDS each) per CU; for larger problems whole multiples of that keep the tail short
     int hw = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, e.device) == hipSuccess)
         hw = prop.multiProcessorCount;
     if (hw <= 0)
         hw = 256;
-    const int64_t slots = 2 * (int64_t)hw;
+    int per_cu = 2;
+    if (const char* v = getenv("VMM_BA_SYRK_WG_PER_CU"))
+        per_cu = std::max(1, atoi(v));
+    const int64_t slots = per_cu * (int64_t)hw;
     int64_t n_wg = std::min<int64_t>(units, slots);
     if (units > 64 * slots)
         n_wg = 4 * slots;   // plenty of K tiles per workgroup: several waves of workgroups balance the chip
@@ -159,7 +162,7 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
     if ((rc = dev_alloc(e, &p.tile_bj, bj.size()))) return rc;
     if ((rc = dev_alloc(e, &p.wg_seg0, wg_seg0.size()))) return rc;
     if ((rc = dev_alloc(e, &p.tile_seg0, tile_seg0.size()))) return rc;
-    if ((rc = dev_alloc(e, &p.partials, (size_t)std::max(seg, 1) * 4096, false))) return rc;
+    if ((rc = dev_alloc(e, &p.partials, (size_t)std::max(seg, 1) * kST * kST, false))) return rc;
     if ((rc = upload(e, p.tile_bi, bi))) return rc;
     if ((rc = upload(e, p.tile_bj, bj))) return rc;
     if ((rc = upload(e, p.wg_seg0, wg_seg0))) return rc;
@@ -477,14 +480,14 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.n_red = 6 * e.n_f;
     e.n_pad = round_up(e.n_red, kNB);
     e.n_blk = e.n_pad / kNB;
-    e.ldz = e.n_pad + kNB;
+    e.ldz = round_up(e.n_pad + 1, kST);   // >= n_pad + 64; the rank-k update reads whole 128-wide tiles
     e.k_dim = 6 * e.n_e;
     e.k_pad = round_up(e.k_dim, kKT);
     if ((rc = dev_alloc(e, &e.Le, (size_t)36 * e.n_e))) return fail(rc);
     if ((rc = dev_alloc(e, &e.ze, (size_t)6 * e.n_e))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Z, (size_t)e.k_pad * e.ldz))) return fail(rc);
-    // row blocks 0..n_blk (the last one holds the rhs row), column blocks 0..n_blk-1
-    if ((rc = make_syrk_plan(e, e.syrk, e.n_blk + 1, e.n_blk, e.k_pad))) return fail(rc);
+    // 128-row blocks covering rows 0..n_pad (the last one holds the rhs row) and columns 0..n_pad-1
+    if ((rc = make_syrk_plan(e, e.syrk, (e.n_pad + kST) / kST, (e.n_pad + kST - 1) / kST, e.k_pad))) return fail(rc);
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * e.ldz))) return fail(rc);
     if ((rc = setup_lookahead(e, e.n_blk, e.ldz))) return fail(rc);
@@ -870,8 +873,8 @@ int vmm_ba_dense_syrk(int device, int k, int n, const double* Zh, double* C)
         set_error("bad argument");
         return VMM_BA_ERR_ARGUMENT;
     }
-    const int n_pad = round_up(n, kNB), ld = n_pad;
-    const int n_blk = n_pad / kNB;
+    const int n_pad = round_up(n, kST), ld = n_pad;
+    const int n_blk = n_pad / kST;
     const int k_pad = round_up(k, kKT);
     Engine e;
     int rc = make_scratch(e, device, ld);
