@@ -1,0 +1,80 @@
+"""GPU tests of the incremental driver (startReconstruction) and of the mapping command line.
+
+Oracle: the same driver with every bundle adjustment and statistic served by the CPU oracle
+(tests/oracle_reconstructor.py).  Both runs start from the same detections and use the same PnP code, so
+they follow the same sequence of problems; the comparison checks all N+2 GPU solves and the prunings.
+Tolerance: 1e-6 relative on pose parameters per solve (north star); the solves chain, so the final
+comparison allows 1e-5.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _flat(rec):
+    tags = np.array([np.r_[rec.reconstructedTags[t].q, rec.reconstructedTags[t].t] for t in sorted(rec.reconstructedTags)])
+    cams = np.array([np.r_[rec.reconstructedCameras[c].q, rec.reconstructedCameras[c].t]
+                     for c in sorted(rec.reconstructedCameras)])
+    return tags, cams
+
+
+def test_start_reconstruction_matches_oracle_driven_run(tmp_path, capsys):
+    from oracle_reconstructor import OracleReconstructor
+    from visual_marker_mapping_amd import io as vio, synthetic
+    from visual_marker_mapping_amd.tag_reconstructor import TagReconstructor
+    s = synthetic.make_scene(1, visibility=0.6)            # 20 images x 10 tags, ~60 % of the pairs observed
+    synthetic.write_project(s, str(tmp_path))
+    det = vio.readDetectionResult(str(tmp_path / "marker_detections.json"))
+    model = vio.readCameraModel(str(tmp_path / "camera_intrinsics.json"))
+    gpu = TagReconstructor(det)
+    gpu.setCameraModel(model)
+    gpu.startReconstruction(4)
+    out = capsys.readouterr().out
+    assert out.count("Solution ") == len(gpu.reconstructedCameras) + 2      # N + 2 solves (:233, :271, :277)
+    cpu = OracleReconstructor(vio.readDetectionResult(str(tmp_path / "marker_detections.json")))
+    cpu.setCameraModel(model)
+    cpu.startReconstruction(4)
+    assert sorted(gpu.reconstructedTags) == sorted(cpu.reconstructedTags)
+    assert sorted(gpu.reconstructedCameras) == sorted(cpu.reconstructedCameras)
+    tg, cg = _flat(gpu)
+    tc, cc = _flat(cpu)
+    np.testing.assert_allclose(tg, tc, rtol=0, atol=1e-5 * max(1.0, np.abs(tc).max()))
+    np.testing.assert_allclose(cg, cc, rtol=0, atol=1e-5 * max(1.0, np.abs(cc).max()))
+    # near the ground truth: 0.3 px noise on 8075 px focal length at ~10 m
+    for k, t in enumerate(sorted(gpu.reconstructedTags)):
+        assert np.abs(tg[k, 4:] - s.tag_gt[t, 4:]).max() < 5e-3
+
+
+def test_mapping_command_line(tmp_path, capsys):
+    from visual_marker_mapping_amd import io as vio, mapping, synthetic
+    from visual_marker_mapping_amd.tag_reconstructor import TagReconstructor
+    s = synthetic.make_scene(1, n_cams=8, n_tags=6)
+    model, det = synthetic.write_project(s, str(tmp_path))
+    assert mapping.main(["--project_path", str(tmp_path), "--start_tag_id", "2"]) == 0
+    out = capsys.readouterr().out
+    assert "Wrote %s!" % (tmp_path / "reconstruction.json") in out
+    tags, cams, m = vio.parseReconstructions(str(tmp_path / "reconstruction.json"))
+    assert sorted(tags) == list(range(6)) and sorted(cams) == list(range(8)) and m.fx == model.fx
+    # --start_tag_id 2: tag 2 is the fixed origin, exactly at identity
+    assert tags[2].q.tolist() == [1.0, 0.0, 0.0, 0.0] and tags[2].t.tolist() == [0.0, 0.0, 0.0]
+    # same answer as the class driven directly
+    rec = TagReconstructor(det)
+    rec.setCameraModel(model)
+    rec.setOriginTagId(2)
+    rec.startReconstruction(1)
+    for t in tags:
+        assert np.array_equal(tags[t].q, rec.reconstructedTags[t].q) and np.array_equal(tags[t].t, rec.reconstructedTags[t].t)
+    # an existing output file is not overwritten without consent; like the reference, exceptions are printed
+    # and the exit code stays 0 (main_mapping.cpp:90-95)
+    import io as _pyio
+    import sys
+    old = sys.stdin
+    sys.stdin = _pyio.StringIO("n\n")
+    try:
+        assert mapping.main(["--project_path", str(tmp_path)]) == 1
+    finally:
+        sys.stdin = old
+    assert "Exiting!" in capsys.readouterr().out
+    assert mapping.main(["--project_path", str(tmp_path / "missing"), "--yes"]) == 0
+    assert "An exception occurred:" in capsys.readouterr().out

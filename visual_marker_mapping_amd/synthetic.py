@@ -80,3 +80,24 @@ def make_scene(config=2, **overrides):
                           obs_cam=obs_cam[:n].copy(), obs_tag=obs_tag[:n].copy(),
                           obs_px=obs_px[:n].copy(), noise_px=cfg.noise_px,
                           robustify=bool(cfg.outlier_frac > 0), visibility=cfg.visibility)
+
+
+def write_project(scene, directory):
+    """Writes the scene as a project directory of the reference's mapping step (SURVEY.md 8(d) "emitted
+    files"): camera_intrinsics.json and marker_detections.json in the reference's formats (Appendix B),
+    plus ground_truth.json and initial_state.json (reconstruction.json layout) for tests."""
+    from . import io as _io
+    from .tag_reconstructor import Camera, CameraModel, ReconstructedTag, detection_result_from_arrays
+    os.makedirs(directory, exist_ok=True)
+    model = CameraModel(*[float(v) for v in scene.intr], distortionCoefficients=scene.dist,
+                        verticalResolution=4000, horizontalResolution=6000)
+    _io.writeCameraModel(model, os.path.join(directory, "camera_intrinsics.json"))
+    det = detection_result_from_arrays(scene.obs_cam, scene.obs_tag, scene.obs_px, scene.tag_wh, len(scene.cam_gt))
+    _io.writeDetectionResult(det, os.path.join(directory, "marker_detections.json"))
+    for name, cams, tags in (("ground_truth.json", scene.cam_gt, scene.tag_gt),
+                             ("initial_state.json", scene.cam_init, scene.tag_init)):
+        rt = {t: ReconstructedTag(t, "apriltag_36h11", tags[t, :4], tags[t, 4:], scene.tag_wh[t, 0], scene.tag_wh[t, 1])
+              for t in range(len(tags))}
+        rc = {c: Camera(c, cams[c, :4], cams[c, 4:]) for c in range(len(cams))}
+        _io.exportReconstructions(os.path.join(directory, name), rt, rc, model)
+    return model, det

@@ -6,9 +6,9 @@ so that the parity tests read like tests of the reference class.  The bodies of 
 pack the std::map-style state into flat arrays and call libvmm_ba.so (MI355X); nothing here computes
 residuals or solves on the CPU.
 
-Out of scope in this round (SURVEY.md section 8(f) "next" rows): startReconstruction's incremental
-driver (it needs the OpenCV PnP initialisation, src/TagReconstructor.cpp:156,167-230) -- callers
-provide initial poses through setReconstructedTags / setReconstructedCameras instead.
+startReconstruction (the incremental driver) is host logic around the hot
+path; its two PnP initialisations (OpenCV in the reference) live in pnp.py.  Callers may also provide
+initial poses through setReconstructedTags / setReconstructedCameras and call doBundleAdjustment directly.
 """
 import math
 
@@ -183,10 +183,106 @@ class TagReconstructor:
         self.originTagId = int(originTagId)
 
     def startReconstruction(self, numThreads=1):
-        raise NotImplementedError(
-            "startReconstruction (src/TagReconstructor.cpp:86-278) is the incremental driver around the hot "
-            "path; it needs OpenCV's PnP for initial poses and is a SURVEY.md 8(f) 'next' row.  Provide "
-            "initial poses with setReconstructedTags/setReconstructedCameras and call doBundleAdjustment.")
+        """The incremental driver, src/TagReconstructor.cpp:86-278: origin tag at identity; the image that
+        sees the origin tag and the most tags first; then per image: camera pose from the already
+        reconstructed tags (PnP+RANSAC), every new tag seen in >= 2 images from its own four corners (PnP),
+        robust bundle adjustment (400 iterations), pruning of tags above 2 px; next = the image with the most
+        reconstructed tags.  Ends with BA(1500, robust), both prunings, BA(1500, plain, summary).
+
+        The bundle adjustments and the reprojection statistics run on the MI355X through libvmm_ba; the two
+        PnP initialisations are host code in pnp.py (OpenCV's role in the reference)."""
+        from . import pnp as _pnp
+        if self.originTagId == -1:
+            self.originTagId = self.getLowestTag()
+        intr = (self.camModel.fx, self.camModel.fy, self.camModel.cx, self.camModel.cy)
+        dist = tuple(float(v) for v in self.camModel.distortionCoefficients)
+        whichImagesObserveTag, tagsInImage, obsOfImage = {}, {}, {}
+        for ob in self.detectionResults_.tagObservations:
+            whichImagesObserveTag.setdefault(ob.tagId, set()).add(ob.imageId)
+            tagsInImage.setdefault(ob.imageId, set()).add(ob.tagId)
+            obsOfImage.setdefault(ob.imageId, []).append(ob)
+        imageFilenames = {img.imageId: img.filename for img in self.detectionResults_.images}
+        tagById = {t.tagId: t for t in self.detectionResults_.tags}
+
+        # the image with the most markers among those that see the origin tag (:117-127)
+        maxObservations, curImageId = 0, -1
+        for imageId in sorted(whichImagesObserveTag.get(self.originTagId, ())):
+            if len(tagsInImage[imageId]) > maxObservations:
+                curImageId, maxObservations = imageId, len(tagsInImage[imageId])
+        if self.originTagId not in tagById:
+            raise RuntimeError("Could not use tag with id %d as origin tag, because it was not detected."
+                               % self.originTagId)
+        o = tagById[self.originTagId]
+        self.reconstructedTags.setdefault(self.originTagId, ReconstructedTag(
+            id=self.originTagId, tagType=o.tagType, tagWidth=o.width, tagHeight=o.height))
+
+        while True:
+            print("Reconstructing image %d/%d | %s with id: %d" % (
+                len(self.reconstructedCameras), len(self.detectionResults_.images),
+                imageFilenames.get(curImageId, ""), curImageId))
+            pose = self.computeRelativeCameraPoseFromImg(curImageId, intr, dist, obsOfImage.get(curImageId, []))
+            if pose is None:
+                raise RuntimeError("No reconstructed tags in image found. To reconstruct the image pose "
+                                   "already reconstructed markers are needed. This should NOT happen.")
+            newCamera = Camera(cameraId=curImageId, q=pose[0], t=pose[1])
+            print("   Initialized camera with id %d" % curImageId)
+            self.reconstructedCameras.setdefault(curImageId, newCamera)
+            cam = self.reconstructedCameras[curImageId]
+            Rc, tc = _quat_to_R(cam.q), cam.t
+            for ob in obsOfImage.get(curImageId, []):
+                if ob.tagId in self.reconstructedTags:
+                    continue
+                if len(whichImagesObserveTag[ob.tagId]) < 2:
+                    print("   Skipping reconstruction of tag %d: Only observed once!" % ob.tagId)
+                    continue
+                d = tagById[ob.tagId]
+                recTag = ReconstructedTag(id=ob.tagId, tagType=d.tagType, tagWidth=d.width, tagHeight=d.height)
+                R, t = _pnp.solvePnP(recTag.computeLocalMarkerCorners3D(), ob.corners, intr, dist)   # tag -> camera
+                # TMarker2World = extrinsic^-1 * T  (:213-221)
+                recTag.setQuat(_pnp.quat_from_R(Rc.T @ R))
+                recTag.t = Rc.T @ (t - tc)
+                self.reconstructedTags[ob.tagId] = recTag
+                print("   Initialized tag with id %d" % ob.tagId)
+
+            self.doBundleAdjustment(400, numThreads, True)
+            self.removeBadMarkers(2.0)
+
+            # next: the unreconstructed image with the most reconstructed tags (:236-259)
+            maxPairs = 0
+            for img in self.detectionResults_.images:
+                if img.imageId in self.reconstructedCameras:
+                    continue
+                n = sum(1 for tid in tagsInImage.get(img.imageId, ()) if tid in self.reconstructedTags)
+                if n > maxPairs:
+                    maxPairs, curImageId = n, img.imageId
+            if maxPairs == 0:
+                break
+            print("----------------------------------------------------------")
+
+        print("Starting final bundle adjustment")
+        self.doBundleAdjustment(1500, numThreads, True, False)
+        self.removeBadMarkers(2.0)
+        self.removeBadCameras(2.0)
+        self.doBundleAdjustment(1500, numThreads, False, True)
+
+    def computeRelativeCameraPoseFromImg(self, imageId, intr, dist, observations=None):
+        """src/TagReconstructor.cpp:280-312: (q, t) of the camera from every correspondence between this
+        image's detected corners and the corners of already reconstructed tags, or None without any."""
+        from . import pnp as _pnp
+        if observations is None:
+            observations = [ob for ob in self.detectionResults_.tagObservations if ob.imageId == imageId]
+        X, px = [], []
+        for ob in observations:
+            tag = self.reconstructedTags.get(ob.tagId)
+            if tag is None:
+                continue
+            X.extend(tag.computeMarkerCorners3D())
+            px.extend(np.asarray(ob.corners, np.float64).reshape(4, 2))
+        print("   Reconstructing camera pose from %d 2d/3d correspondences" % len(px))
+        if not px:
+            return None
+        R, t = _pnp.solvePnPRansac(np.asarray(X), np.asarray(px), intr, dist, seed=int(imageId) & 0x7FFFFFFF)
+        return _pnp.quat_from_R(R), t
 
     def moveTagIntoOrigin(self, tagId):
         """src/TagReconstructor.cpp:314-338 (applies the same map to tags AND cameras, as the reference does)."""
