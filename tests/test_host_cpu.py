@@ -125,7 +125,7 @@ def test_tag_quad_and_getters_match_reference_definitions():
     assert rec.getLowestTag() == 4 and rec.originTagId == -1
     with pytest.raises(RuntimeError):
         rec.moveTagIntoOrigin(4)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="No reconstructed tags in image found"):   # :158-161
         rec.startReconstruction()
 
 
