@@ -36,7 +36,8 @@ enum {
     VMM_BA_ERR_ARGUMENT = 1,   /* bad sizes / indices / null pointers */
     VMM_BA_ERR_HIP = 2,        /* a HIP runtime call failed (no device, OOM, launch failure) */
     VMM_BA_ERR_COLLECTIVE = 3, /* the user-supplied all-reduce callback reported failure */
-    VMM_BA_ERR_STATE = 4       /* call sequence error */
+    VMM_BA_ERR_STATE = 4,      /* call sequence error */
+    VMM_BA_ERR_NUMERIC = 5     /* rank-deficient Jacobian: no covariance (ceres::Covariance::Compute == false) */
 };
 
 /* which pose family is eliminated by block Gaussian elimination before the dense reduced solve.
@@ -185,6 +186,14 @@ int vmm_ba_cost(vmm_ba_handle h, int robustify, double huber_a, double* cost);
  * the caller's observation order (:447-451).  Any output may be NULL. */
 int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per_tag_mean,
                               double* avg, double* per_corner);
+
+/* Replaces the ceres::Covariance block of doBundleAdjustment (src/TagReconstructor.cpp:744-783):
+ * cov[9*t .. 9*t+8] = row-major 3x3 covariance of tag t's translation = the corresponding block of
+ * (J^T J)^-1 in tangent coordinates at the current state, J with the loss applied when robustify != 0
+ * (Covariance::Options::apply_loss_function defaults to true).  Constant (origin) and residual-free tags
+ * get zeros, as Ceres reports for constant blocks.  Computed from the Schur factor of the undamped,
+ * unscaled normal equations; VMM_BA_ERR_NUMERIC if they are not positive definite.  Single-GPU handles. */
+int vmm_ba_tag_translation_covariance(vmm_ba_handle h, int robustify, double huber_a, double* cov);
 
 /* Replaces CameraModel::projectPoint (src/CameraModel.cpp:6-26) for n camera-frame points. */
 int vmm_ba_project_points(const double intr[4], const double dist[5], int64_t n,

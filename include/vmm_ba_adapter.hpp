@@ -125,6 +125,11 @@ int doBundleAdjustment(TagMap& tags, CamMap& cams, const Detection& det, const C
     int rc = vmm_ba_solve(h, &o, &s);
     if (rc == VMM_BA_OK)
         rc = vmm_ba_get_state(h, p.cam_qt.data(), p.tag_qt.data());
+    std::vector<double> cov;                                          // :744-760
+    if (rc == VMM_BA_OK && printSummary) {
+        cov.resize(9 * p.tag_ids.size());
+        rc = vmm_ba_tag_translation_covariance(h, o.robustify, o.huber_a, cov.data());
+    }
     vmm_ba_destroy(h);
     check(rc, "vmm_ba_solve");
     for (size_t k = 0; k < p.cam_ids.size(); ++k) {
@@ -141,6 +146,21 @@ int doBundleAdjustment(TagMap& tags, CamMap& cams, const Detection& det, const C
     if (printSummary)                                                 // :741-742 (FullReport stand-in)
         std::cout << "vmm_ba: iterations " << s.iterations << ", initial cost " << s.initial_cost
                   << ", final cost " << s.final_cost << ", solver time " << s.time_solve_s << " s" << std::endl;
+    if (printSummary) {                                               // :761-782
+        double avg[3] = { 0.0, 0.0, 0.0 };
+        for (size_t k = 0; k < p.tag_ids.size(); ++k) {
+            const double* c = &cov[9 * k];
+            const double sd[3] = { std::sqrt(c[0]), std::sqrt(c[4]), std::sqrt(c[8]) };
+            std::cout << "StdDev of tag " << p.tag_ids[k] << ": " << sd[0] << " " << sd[1] << " " << sd[2]
+                      << " | StdDevNorm: " << std::sqrt(std::sqrt(sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]))
+                      << std::endl;
+            avg[0] += c[0];
+            avg[1] += c[4];
+            avg[2] += c[8];
+        }
+        const double n = (double)p.tag_ids.size();
+        std::cout << "Marker Position RMS = " << std::sqrt(avg[0] / n + avg[1] / n + avg[2] / n) << std::endl;
+    }
     return s.termination_type;
 }
 

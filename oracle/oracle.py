@@ -175,3 +175,14 @@ def reprojection_stats(scene):
     corner = np.zeros((len(scene.obs_cam), 8))
     lib().vo_reprojection_stats(C.byref(p), _dp(pc), _dp(pt), C.byref(avg), _dp(corner))
     return pc, pt, avg.value, corner
+
+
+def tag_translation_covariance(scene, opts=None):
+    """(n_tags, 3, 3) covariance blocks of the tag translations; raises if J^T J is singular."""
+    opts = opts or default_options()
+    p = scene.c_problem()
+    cov = np.zeros((len(scene.tag_qt), 3, 3))
+    if lib().vo_tag_translation_covariance(C.byref(p), C.byref(opts), _dp(cov)) != 0:
+        raise RuntimeError("J^T J is not positive definite")
+    return cov
+

@@ -1128,3 +1128,87 @@ void vo_reprojection_stats(const vo_problem* p, double* per_cam_mean, double* pe
     free(nc);
     free(nt);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Covariance of the tag translations (TagReconstructor.cpp:744-783: ceres::Covariance on the (t, t)
+ * blocks of every reconstructed tag): the 3x3 diagonal blocks of (J^T J)^-1 in tangent coordinates,
+ * J corrected by the loss when robustify is set (Covariance::Options::apply_loss_function = true).
+ * Constant / residual-free blocks get zeros.  Dense Cholesky of the full normal matrix -- small cases.
+ * Returns nonzero when J^T J is not positive definite.
+ * ---------------------------------------------------------------------------------------------- */
+int vo_tag_translation_covariance(const vo_problem* p, const vo_options* o, double* cov)
+{
+    const int n_c = p->n_cams, n_t = p->n_tags, n_obs = p->n_obs;
+    work w;
+    memset(&w, 0, sizeof(w));
+    w.n_c = n_c;
+    w.n_t = n_t;
+    w.n_obs = n_obs;
+    w.n_pose = n_c + n_t;
+    w.n_tan = 6 * w.n_pose;
+    const int n = w.n_tan;
+    w.J = (double*)malloc((size_t)96 * (n_obs > 0 ? n_obs : 1) * sizeof(double));
+    w.r = (double*)malloc((size_t)8 * (n_obs > 0 ? n_obs : 1) * sizeof(double));
+    w.g = (double*)calloc((size_t)n + 1, sizeof(double));
+    w.active = (int*)calloc((size_t)w.n_pose + 1, sizeof(int));
+    for (int i = 0; i < n_obs; ++i) {
+        w.active[p->obs_cam[i]] = 1;
+        w.active[n_c + p->obs_tag[i]] = 1;
+    }
+    if (p->fixed_tag >= 0 && p->fixed_tag < n_t)
+        w.active[n_c + p->fixed_tag] = 0;
+    double cost = 0.0;
+    eval_full(p, o, &w, p->cam_qt, p->tag_qt, &cost);
+    double* D2 = (double*)calloc((size_t)n + 1, sizeof(double));
+    for (int q = 0; q < w.n_pose; ++q)
+        for (int k = 0; k < 6; ++k)
+            D2[6 * q + k] = w.active[q] ? 0.0 : 1.0;
+    /* H = J^T J (+ unit diagonal on inactive blocks), factored once */
+    double* H = (double*)calloc((size_t)n * n, sizeof(double));
+    for (int i = 0; i < n_obs; ++i) {
+        const int c = p->obs_cam[i], t = p->obs_tag[i];
+        const double* Jc = w.J + (size_t)96 * i;
+        const double* Jt = Jc + 48;
+        const int ic = 6 * c, it = 6 * (n_c + t);
+        for (int row = 0; row < 8; ++row) {
+            const double* jc = Jc + 6 * row;
+            const double* jt = Jt + 6 * row;
+            for (int a = 0; a < 6; ++a) {
+                for (int q = 0; q <= a; ++q) {
+                    H[(size_t)(ic + a) * n + ic + q] += jc[a] * jc[q];
+                    H[(size_t)(it + a) * n + it + q] += jt[a] * jt[q];
+                }
+                for (int q = 0; q < 6; ++q)
+                    H[(size_t)(it + a) * n + ic + q] += jt[a] * jc[q];
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        H[(size_t)i * n + i] += D2[i];
+    int fail = chol_lower(H, n, n);
+    double* x = (double*)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    for (int t = 0; t < n_t; ++t) {
+        double* out = cov + 9 * t;
+        if (fail || !w.active[n_c + t]) {
+            for (int k = 0; k < 9; ++k)
+                out[k] = 0.0;
+            continue;
+        }
+        const int base = 6 * (n_c + t);
+        for (int a = 0; a < 3; ++a) {
+            memset(x, 0, (size_t)n * sizeof(double));
+            x[base + a] = 1.0;
+            chol_solve(H, n, n, x);
+            for (int b = 0; b < 3; ++b)
+                out[3 * b + a] = x[base + b];
+        }
+    }
+    free(x);
+    free(H);
+    free(D2);
+    free(w.J);
+    free(w.r);
+    free(w.g);
+    free(w.active);
+    return fail;
+}

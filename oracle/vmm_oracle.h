@@ -131,6 +131,10 @@ void vo_reprojection_stats(const vo_problem* p, double* per_cam_mean, double* pe
                            double* avg, double* per_corner);
 
 /* CameraModel::projectPoint, CameraModel.cpp:6-26. */
+/* Covariance of the tag translations: cov[9*t..] = 3x3 block of (J^T J)^-1 (TagReconstructor.cpp:744-783).
+ * Returns nonzero if J^T J is not positive definite. */
+int vo_tag_translation_covariance(const vo_problem* p, const vo_options* o, double* cov);
+
 void vo_project_point(const double intr[4], const double dist[5], const double pc[3], double uv[2]);
 
 #ifdef __cplusplus

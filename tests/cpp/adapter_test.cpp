@@ -49,7 +49,7 @@ int main()
         det.tagObservations.push_back(ob);
     }
     try {
-        const int term = vmm_ba_adapter::doBundleAdjustment(tags, cams, det, cm, origin, 400, 1, true, false);
+        const int term = vmm_ba_adapter::doBundleAdjustment(tags, cams, det, cm, origin, 400, 1, true, true);
         const auto st = vmm_ba_adapter::reprojectionStatistics(tags, cams, det, cm, true);
         const auto uv = vmm_ba_adapter::projectPoint(cm, 0.3, -0.2, 2.5);
         printf("TERM %d\n", term);

@@ -52,10 +52,14 @@ def test_adapter_matches_python_engine():
     r = subprocess.run([EXE], input=_scene_text(s, tag_ids, cam_ids), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Solution 0" in r.stdout
-    cams, tags, avg = {}, {}, None
+    cams, tags, avg, stddev, rms = {}, {}, None, {}, None
     for line in r.stdout.splitlines():
         f = line.split()
-        if f[0] == "CAM":
+        if line.startswith("StdDev of tag"):           # src/TagReconstructor.cpp:771-772
+            stddev[int(f[3].rstrip(":"))] = np.array(f[4:7], float)
+        elif line.startswith("Marker Position RMS ="):   # :781
+            rms = float(f[-1])
+        elif f[0] == "CAM":
             cams[int(f[1])] = np.array(f[2:], float)
         elif f[0] == "TAG":
             tags[int(f[1])] = np.array(f[2:], float)
@@ -65,7 +69,12 @@ def test_adapter_matches_python_engine():
     ba.solve(eng.default_options(robustify=1))
     cam, tag = ba.get_state()
     _, _, ref_avg, _ = ba.reprojection_stats()
+    cov = ba.tag_translation_covariance(robustify=True)
     ba.close()
+    assert sorted(stddev) == tag_ids and stddev[tag_ids[0]].tolist() == [0.0, 0.0, 0.0]
+    for k, t in enumerate(tag_ids):                     # default ostream precision: 6 significant digits
+        np.testing.assert_allclose(stddev[t], np.sqrt(np.diag(cov[k])), rtol=6e-6, atol=0)
+    np.testing.assert_allclose(rms, np.sqrt(np.trace(cov.sum(axis=0)) / len(tag_ids)), rtol=6e-6)
     np.testing.assert_array_equal(np.array([cams[c] for c in cam_ids]), cam)   # same library, same bits
     np.testing.assert_array_equal(np.array([tags[t] for t in tag_ids]), tag)
     assert avg == ref_avg and ncorner == 4 * s.n_obs

@@ -32,6 +32,8 @@ def test_start_reconstruction_matches_oracle_driven_run(tmp_path, capsys):
     gpu.startReconstruction(4)
     out = capsys.readouterr().out
     assert out.count("Solution ") == len(gpu.reconstructedCameras) + 2      # N + 2 solves (:233, :271, :277)
+    # the last solve prints the covariance report (:744-783)
+    assert out.count("StdDev of tag ") == len(gpu.reconstructedTags) and "Marker Position RMS = " in out
     cpu = OracleReconstructor(vio.readDetectionResult(str(tmp_path / "marker_detections.json")))
     cpu.setCameraModel(model)
     cpu.startReconstruction(4)
@@ -41,6 +43,13 @@ def test_start_reconstruction_matches_oracle_driven_run(tmp_path, capsys):
     tc, cc = _flat(cpu)
     np.testing.assert_allclose(tg, tc, rtol=0, atol=1e-5 * max(1.0, np.abs(tc).max()))
     np.testing.assert_allclose(cg, cc, rtol=0, atol=1e-5 * max(1.0, np.abs(cc).max()))
+    from oracle import oracle as O
+    p = gpu._pack(for_ba=True)
+    sc = O.Scene(p["intr"], p["dist"], p["cam_qt"], p["tag_qt"], p["tag_wh"], p["fixed"], p["obs_cam"], p["obs_tag"],
+                 p["obs_px"])
+    ref = O.tag_translation_covariance(sc, O.default_options(robustify=0))
+    for k, t in enumerate(p["tag_ids"]):
+        np.testing.assert_allclose(gpu.lastCovariances[t], ref[k], rtol=0, atol=1e-5 * max(np.abs(ref[k]).max(), 1e-300))
     # near the ground truth: 0.3 px noise on 8075 px focal length at ~10 m
     for k, t in enumerate(sorted(gpu.reconstructedTags)):
         assert np.abs(tg[k, 4:] - s.tag_gt[t, 4:]).max() < 5e-3

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VMM_BA_LIB selects another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("VMM_BA_LIB") or os.path.join(_HERE, "libvmm_ba.so")
 
-OK, ERR_ARGUMENT, ERR_HIP, ERR_COLLECTIVE, ERR_STATE = 0, 1, 2, 3, 4
+OK, ERR_ARGUMENT, ERR_HIP, ERR_COLLECTIVE, ERR_STATE, ERR_NUMERIC = 0, 1, 2, 3, 4, 5
 ELIM_AUTO, ELIM_TAGS, ELIM_CAMERAS = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 
@@ -17,7 +17,7 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 EXPORTS = ["vmm_ba_last_error", "vmm_ba_abi_version", "vmm_ba_default_options",
            "vmm_ba_default_create_options", "vmm_ba_create", "vmm_ba_destroy", "vmm_ba_set_state",
            "vmm_ba_get_state", "vmm_ba_set_allreduce", "vmm_ba_solve", "vmm_ba_cost",
-           "vmm_ba_reprojection_stats", "vmm_ba_project_points", "vmm_ba_eval_blocks",
+           "vmm_ba_reprojection_stats", "vmm_ba_tag_translation_covariance", "vmm_ba_project_points", "vmm_ba_eval_blocks",
            "vmm_ba_dense_spd_solve", "vmm_ba_dense_syrk", "vmm_ba_time_kernels"]
 
 
@@ -99,6 +99,7 @@ def lib():
         L.vmm_ba_cost.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
         L.vmm_ba_reprojection_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.POINTER(C.c_double), C.c_void_p]
+        L.vmm_ba_tag_translation_covariance.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
         L.vmm_ba_project_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                             C.c_int]
         L.vmm_ba_eval_blocks.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double),

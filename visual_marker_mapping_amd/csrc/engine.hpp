@@ -166,6 +166,12 @@ void launch_syrk_plan(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz
 void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int ld, int n_rows, double* S);
 // kernels_chol.hip
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl);
+void launch_chol_inverse(Engine& e, int k);
+// kernels_cov.hip
+void launch_cov_prepare(Engine& e);
+void launch_cov_rhs(Engine& e, double* B, int ldb, bool identity_rhs);
+void launch_cov_trsm(Engine& e, double* B, int ldb, int n_chunks, bool identity_rhs);
+void launch_cov_gram(Engine& e, const double* X, int ldb, double* cov_dev);
 // kernels_lm.hip
 void launch_zero_unless_eval(Engine& e, double* buf, size_t n);
 void launch_iter_begin(Engine& e, const double* src);

@@ -700,6 +700,23 @@ __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restric
         chol_inverse_wg(Ld + (int64_t)(k - 1) * 4096, dinv + (k - 1) * kNB, Linv + (int64_t)(k - 1) * 4096, smem);
 }
 
+// The look-ahead launches leave the last diagonal block uninverted (the chain solves it directly); the
+// covariance forward substitution needs all of them.
+__global__ __launch_bounds__(256) void k_chol_inverse(const LmCtl* ctl, const double* __restrict__ Ld,
+                                                      const double* __restrict__ dinv, double* __restrict__ Linv, int k)
+{
+    if (ctl->done || ctl->lin_fail)
+        return;
+    __shared__ __attribute__((aligned(16))) double smem[64 * kLd + 64];
+    chol_inverse_wg(Ld + (int64_t)k * 4096, dinv + k * kNB, Linv + (int64_t)k * 4096, smem);
+}
+
+void launch_chol_inverse(Engine& e, int k)
+{
+    hipLaunchKernelGGL(k_chol_inverse, dim3(1), dim3(256), 0, e.stream, (const LmCtl*)e.ctl, (const double*)e.Ldiag,
+                       (const double*)e.dinv, e.Linv, k);
+}
+
 static int update_tiles(int n_blk, int k)   // tiles of the trailing update of panel k: columns >= k+2
 {
     int tiles = 0;

@@ -725,6 +725,68 @@ int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per
     return VMM_BA_OK;
 }
 
+int vmm_ba_tag_translation_covariance(vmm_ba_handle h, int robustify, double huber_a, double* cov)
+{
+    if (!h || !cov) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (e.multi) {
+        set_error("tag_translation_covariance is a single-GPU entry point");
+        return VMM_BA_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(e.device));
+    if (e.n_obs == 0 || e.n_tags == 0) {
+        memset(cov, 0, sizeof(double) * 9 * (size_t)e.n_tags);
+        return VMM_BA_OK;
+    }
+    vmm_ba_options o;
+    vmm_ba_default_options(&o);
+    o.robustify = robustify;
+    o.huber_a = huber_a;
+    init_ctl(*e.ctl_host, o, 0);
+    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+    // the iteration's kernels on the undamped, unscaled system: H blocks, Z, S = L L^T (+ block inverses)
+    launch_eval_passes(e, false, robustify, huber_a, false);
+    launch_cov_prepare(e);
+    launch_elim(e);
+    launch_syrk_reduced(e);
+    launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
+    launch_chol_inverse(e, e.n_blk - 1);
+    // L X = B with B = I (tags kept) or Z^T (tags eliminated), then per-tag Gram blocks
+    const bool identity_rhs = e.elim_cams;
+    const int n_rhs = identity_rhs ? e.n_pad : e.k_dim;
+    const int ldb = round_up(n_rhs, 64);
+    double *B = nullptr, *cov_dev = nullptr;
+    hipError_t err = hipMalloc((void**)&B, sizeof(double) * (size_t)e.n_pad * ldb);
+    if (err == hipSuccess) err = hipMalloc((void**)&cov_dev, sizeof(double) * 9 * (size_t)e.n_tags);
+    if (err == hipSuccess) err = hipMemsetAsync(B, 0, sizeof(double) * (size_t)e.n_pad * ldb, e.stream);
+    if (err == hipSuccess) {
+        launch_cov_rhs(e, B, ldb, identity_rhs);
+        launch_cov_trsm(e, B, ldb, ldb / 64, identity_rhs);
+        launch_cov_gram(e, B, ldb, cov_dev);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(cov, cov_dev, sizeof(double) * 9 * (size_t)e.n_tags, hipMemcpyDeviceToHost, e.stream);
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream);
+    if (err == hipSuccess)
+        err = hipStreamSynchronize(e.stream);
+    (void)hipFree(B);
+    (void)hipFree(cov_dev);
+    if (err != hipSuccess) {
+        set_error(std::string("tag_translation_covariance: ") + hipGetErrorString(err));
+        return VMM_BA_ERR_HIP;
+    }
+    if (e.ctl_host->lin_fail) {
+        set_error("tag_translation_covariance: J^T J is not positive definite (rank-deficient Jacobian)");
+        return VMM_BA_ERR_NUMERIC;
+    }
+    return VMM_BA_OK;
+}
+
 int vmm_ba_project_points(const double intr[4], const double dist[5], int64_t n, const double* points_cam,
                           double* uv, int device)
 {

@@ -125,6 +125,14 @@ class BundleAdjuster:
         _lib.check(_lib.lib().vmm_ba_reprojection_stats(self._h, _ptr(pc), _ptr(pt), C.byref(avg), _ptr(corner)))
         return pc, pt, avg.value, corner
 
+    def tag_translation_covariance(self, robustify=False, huber_a=1.0):
+        """(n_tags, 3, 3) covariance blocks of the tag translations at the current state -- the
+        ceres::Covariance block of /root/reference/src/TagReconstructor.cpp:744-783."""
+        cov = np.zeros((self.n_tags, 3, 3))
+        _lib.check(_lib.lib().vmm_ba_tag_translation_covariance(self._h, int(bool(robustify)), float(huber_a),
+                                                               _ptr(cov)))
+        return cov
+
     # ---- diagnostics ----
     def eval_blocks(self, robustify=True, huber_a=1.0, want_W=True):
         V, U = np.zeros((self.n_cams, 6, 6)), np.zeros((self.n_tags, 6, 6))

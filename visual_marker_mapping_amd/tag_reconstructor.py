@@ -149,6 +149,7 @@ class TagReconstructor:
         self.camModel = CameraModel()
         self.device = int(device)
         self.lastSummary = None                                # summary of the last doBundleAdjustment
+        self.lastCovariances = None                            # tag id -> 3x3 (last printSummary call)
 
     # -- trivial accessors (src/TagReconstructor.cpp:75-84, 818-842) --
     def getLowestTag(self):
@@ -359,6 +360,7 @@ class TagReconstructor:
                                            num_threads=int(ceresThreads))
             summary = ba.solve(opts, trace_capacity=int(maxNumIterations) + 2 if printSummary else 0)
             cam, tag = ba.get_state()
+            cov = ba.tag_translation_covariance(robustify, opts.huber_a) if printSummary else None   # :744-760
         finally:
             ba.close()
         for k, cid in enumerate(p["cam_ids"]):
@@ -377,7 +379,18 @@ class TagReconstructor:
                     it["relative_decrease"], it["trust_region_radius"]))
             print("Cost: initial %.6e final %.6e; iterations %d; time in solver %.4f s" % (
                 summary["initial_cost"], summary["final_cost"], summary["iterations"], summary["time_solve_s"]))
-            # the covariance report of :744-783 (stdout only) is a SURVEY.md 8(f) 'next' row
+            # covariance report, :761-782 (Eigen prints a row vector with single spaces, 6 significant digits)
+            self.lastCovariances = {}
+            avg_diag = np.zeros(3)
+            for k, tid in enumerate(p["tag_ids"]):
+                self.lastCovariances[tid] = cov[k].copy()
+                diag = np.diag(cov[k])
+                std = np.sqrt(diag)
+                print("StdDev of tag %d: %s | StdDevNorm: %s" % (
+                    tid, " ".join("%.6g" % v for v in std), "%.6g" % math.sqrt(np.linalg.norm(std))))
+                avg_diag += diag
+            avg_diag /= len(p["tag_ids"])
+            print("Marker Position RMS = %.6g" % np.linalg.norm(np.sqrt(avg_diag)))
 
     # -- reprojection statistics + pruning (src/TagReconstructor.cpp:340-455, 786-816) --
     def _stats(self, per_corner):
