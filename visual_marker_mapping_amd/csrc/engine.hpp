@@ -72,6 +72,7 @@ struct SyrkPlan {
 
 struct Engine {
     int device = 0;
+    int n_cu = 256;                 // compute units of the device (workgroup counts of the persistent loops)
     hipStream_t stream = nullptr;
     int rank = 0, world = 1;
     bool multi = false;             // world > 1 (or forced for tests): staging buffers, eager launches, all-reduces
@@ -141,6 +142,7 @@ struct Engine {
     int graph_robustify = -1;
     double graph_huber_a = 0.0;
     bool use_graph = true;
+    bool launched_eagerly = false;  // the handle's first iteration is enqueued without capture
 
     std::vector<void*> allocs;
 };

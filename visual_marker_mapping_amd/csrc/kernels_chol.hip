@@ -21,7 +21,7 @@
 namespace vmm {
 
 #ifdef VMM_STAMPS
-__device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_stamps[64];
 #define STAMP(slot)                                                                  \
     do {                                                                             \
         if (blockIdx.x == 1 && threadIdx.x == 0 && k == 1) {                         \
@@ -29,7 +29,13 @@ __device__ unsigned long long g_stamps[32];
             g_stamps[16 + slot] = __builtin_amdgcn_s_memrealtime();                  \
         }                                                                            \
     } while (0)
+#define USTAMP(slot)                                                                 \
+    do {                                                                             \
+        if (u == 0 && threadIdx.x == 0 && k == 1 && t == u + n_wg)                   \
+            g_stamps[(slot)] = __builtin_amdgcn_s_memtime();                         \
+    } while (0)
 #else
+#define USTAMP(slot)
 #define STAMP(slot)
 #endif
 #ifdef VMM_STAMPS
@@ -332,7 +338,7 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
 }
 
 constexpr int kPanelSmem = 64 * kLdT + 4 * 64 * kPs + 64 + 2 * 64 * kLdsRow;   // doubles (kPs = 9: 4 x 576)
-constexpr int kUpdateSmem = 2 * 64 * kLdsRow;
+constexpr int kUpdateSmem = 4 * 64 * kLdsRow;   // two operand slices, double-buffered: exactly the 160 KB of a CU
 constexpr int kStepSmem = kPanelSmem > kUpdateSmem ? kPanelSmem : kUpdateSmem;
 
 __device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
@@ -354,7 +360,7 @@ __device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S
 #ifdef VMM_STAMPS
 extern "C" int vmm_ba_debug_read_stamps(unsigned long long* out, int n)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 32 ? n : 32));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 64 ? n : 64));
 }
 #endif
 
@@ -363,72 +369,170 @@ extern "C" int vmm_ba_debug_read_stamps(unsigned long long* out, int n)
 // with K = 64 taken from the transposed panel P (64 x ld, row m = panel column m).  One workgroup per
 // 64x64 tile; the whole K extent of both operands (2 x 32 KB) and the C tile are requested up front
 // so the kernel pays one memory latency, then 16 k-steps of four v_mfma_f64_16x16x4_f64 per wave.
-__device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, int n_blk, int k, int t,
-                                               const double* __restrict__ P, double* smem)
+typedef double double2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void update_tile_index(int n_blk, int k, int t, int& bi, int& bj)
 {
-    double* As = smem;
-    double* Bs = smem + 64 * kLdsRow;
     // tile index -> (bi, bj): columns k+2..min(bi, n_blk-1) (block column k+1 is updated lazily by the
     // panel of that column), rows k+2..n_blk
-    int bi = k + 2, bj = k + 2;
+    bi = k + 2;
+    bj = k + 2;
     for (int r = k + 2; r <= n_blk; ++r) {
         const int cnt = ((r < n_blk) ? r : n_blk - 1) - (k + 1);
         if (t < cnt) {
             bi = r;
             bj = k + 2 + t;
-            break;
+            return;
         }
         t -= cnt;
     }
-    const int I0 = bi * kNB, J0 = bj * kNB;
+}
+
+// Workgroup u of n_wg takes the tiles u, u + n_wg, ...  With more tiles than compute units (large reduced
+// systems) the operands of the NEXT tile are requested before the MFMAs of the current one and parked in
+// the other half of the LDS, and the C tile is requested at the start of its own iteration and only added
+// after the 16 k-steps: a tile costs its MFMAs plus one barrier instead of a full memory latency.  No
+// register array lives across the loop back-edge (those end up in scratch).
+__device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, int n_blk, int k, int u, int n_wg,
+                                               int n_tiles, const double* __restrict__ P, double* smem)
+{
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int fk = lane >> 4, fi = lane & 15;
-    double2 va[8], vb[8];
+    if (u >= n_tiles)
+        return;
+    int bi, bj;
+    update_tile_index(n_blk, k, u, bi, bj);
+    {
+        double2 va[8], vb[8];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int idx = it * 256 + tid;
-        const int m = idx >> 5, c = (idx & 31) * 2;
-        va[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + I0 + c);
-        vb[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + J0 + c);   // diagonal tile: same lines again
-    }
-    double4_t acc[2][2];
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            va[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + bi * kNB + c);
+            vb[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + bj * kNB + c);   // diagonal tile: same lines
+        }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[a][b][r] = S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int idx = it * 256 + tid;
-        const int m = idx >> 5, c = (idx & 31) * 2;
-        *reinterpret_cast<double2*>(&As[m * kLdsRow + c]) = va[it];
-        *reinterpret_cast<double2*>(&Bs[m * kLdsRow + c]) = vb[it];
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            *reinterpret_cast<double2*>(&smem[m * kLdsRow + c]) = va[it];
+            *reinterpret_cast<double2*>(&smem[(64 + m) * kLdsRow + c]) = vb[it];
+        }
     }
     __syncthreads();
-    const double* Bp = Bs;
+    int cur = 0;
+    for (int t = u; t < n_tiles; t += n_wg) {
+        const double* As = smem + cur * 128 * kLdsRow;
+        const double* Bs = As + 64 * kLdsRow;
+        const int I0 = bi * kNB, J0 = bj * kNB;
+        // The requests of this tile's C values and of the NEXT tile's operands are issued as volatile asm:
+        // written as plain loads, LLVM sinks them below the MFMA loop to their first use (measured: the
+        // memory latency then adds to the MFMA time, 6.6 us per tile instead of ~3).  The results are only
+        // touched after the matching s_waitcnt below, which takes them as read-write operands.
+        USTAMP(40);
+        double creg[2][2][4];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        const int row = (ks * 4 + fk) * kLdsRow;
-        const double a0 = -As[row + wi * 32 + fi];
-        const double a1 = -As[row + wi * 32 + 16 + fi];
-        const double b0 = Bp[row + wj * 32 + fi];
-        const double b1 = Bp[row + wj * 32 + 16 + fi];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double* src = S + (int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi;
+                    __asm__ volatile("global_load_dwordx2 %0, %1, off" : "=&v"(creg[a][b][r]) : "v"(src) : "memory");
+                }
+        const bool more = t + n_wg < n_tiles;   // workgroup-uniform
+        // next tile = n_wg positions further in the row-major list of lower tiles (rows only get longer, so
+        // this is a couple of steps; a search from the first row costs ~50 cycles per row: 2 us at 94 rows).
+        // The last tile re-requests itself (result unused).
+        int nbi = bi, nbj = bj;
+        if (more) {
+            int off = bj - (k + 2) + n_wg;
+            int cnt = ((nbi < n_blk) ? nbi : n_blk - 1) - (k + 1);
+            while (off >= cnt) {
+                off -= cnt;
+                ++nbi;
+                cnt = ((nbi < n_blk) ? nbi : n_blk - 1) - (k + 1);
+            }
+            nbj = k + 2 + off;
+        }
+        double2v va[8], vb[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            const double* pa = P + (int64_t)m * ld + nbi * kNB + c;
+            const double* pb = P + (int64_t)m * ld + nbj * kNB + c;
+            __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[it]) : "v"(pa) : "memory");
+            __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[it]) : "v"(pb) : "memory");
+        }
+        USTAMP(41);
+        double4_t acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int row = (ks * 4 + fk) * kLdsRow;
+            const double a0 = -As[row + wi * 32 + fi];
+            const double a1 = -As[row + wi * 32 + 16 + fi];
+            const double b0 = Bs[row + wj * 32 + fi];
+            const double b1 = Bs[row + wj * 32 + 16 + fi];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#ifdef VMM_STAMPS
+        __asm__ volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]) : "memory");
+#endif
+        USTAMP(42);
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(creg[0][0][0]), "+v"(creg[0][0][1]), "+v"(creg[0][0][2]), "+v"(creg[0][0][3]),
+                           "+v"(creg[0][1][0]), "+v"(creg[0][1][1]), "+v"(creg[0][1][2]), "+v"(creg[0][1][3]),
+                           "+v"(creg[1][0][0]), "+v"(creg[1][0][1]), "+v"(creg[1][0][2]), "+v"(creg[1][0][3])
+                         :
+                         : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(creg[1][1][0]), "+v"(creg[1][1][1]), "+v"(creg[1][1][2]), "+v"(creg[1][1][3]),
+                           "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]),
+                           "+v"(va[7])
+                         :
+                         : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]),
+                           "+v"(vb[7])
+                         :
+                         : "memory");
+        USTAMP(43);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi]
+                        = creg[a][b][r] + acc[a][b][r];
+        USTAMP(44);
+        // park the next tile's operands in the other half (nobody reads it during this iteration)
+        double* An = smem + (cur ^ 1) * 128 * kLdsRow;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            *reinterpret_cast<double2v*>(&An[m * kLdsRow + c]) = va[it];
+            *reinterpret_cast<double2v*>(&An[(64 + m) * kLdsRow + c]) = vb[it];
+        }
+        USTAMP(45);
+        __syncthreads();
+        USTAMP(46);
+        cur ^= 1;
+        bi = nbi;
+        bj = nbj;
     }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi] = acc[a][b][r];
 }
 
 // One step of L^T y = w (w lives in row n_pad of S).  Launched for kb = n_blk-1 .. 0 with kb+1
@@ -687,15 +791,16 @@ __device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, 
 __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int n_blk,
                                                    int k, int n_panel, double* __restrict__ Pcur,
                                                    const double* __restrict__ Pprev, double* __restrict__ dinv,
-                                                   double* __restrict__ Ld, double* __restrict__ Linv, int n_upd)
+                                                   double* __restrict__ Ld, double* __restrict__ Linv, int n_upd,
+                                                   int n_upd_wg)
 {
     if (ctl->done || ctl->lin_fail)
         return;
     __shared__ __attribute__((aligned(16))) double smem[kStepSmem];
     if ((int)blockIdx.x < n_panel)
         chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, dinv, Ld, smem);
-    else if ((int)blockIdx.x < n_panel + n_upd)
-        chol_update_wg(S, ld, n_blk, k - 1, (int)blockIdx.x - n_panel, Pprev, smem);
+    else if ((int)blockIdx.x < n_panel + n_upd_wg)
+        chol_update_wg(S, ld, n_blk, k - 1, (int)blockIdx.x - n_panel, n_upd_wg, n_upd, Pprev, smem);
     else   // last workgroup of launches k >= 1: invert the diagonal factor of block k-1
         chol_inverse_wg(Ld + (int64_t)(k - 1) * 4096, dinv + (k - 1) * kNB, Linv + (int64_t)(k - 1) * 4096, smem);
 }
@@ -732,10 +837,19 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
         const int n_panel = 1 + (rows_below + 63) / 64;
         const int n_upd = k > 0 ? update_tiles(n_blk, k - 1) : 0;
-        hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd + (k > 0 ? 1 : 0)), dim3(256), 0, e.stream, ctl, S, ld,
+        // all workgroups of a launch resident at once (one per CU: 134 KB of LDS): the update workgroups
+        // share the CUs the panel leaves free and loop over the tiles
+        const int n_upd_wg = std::min(n_upd, std::max(e.n_cu - n_panel - 1, e.n_cu / 4));
+        hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd_wg + (k > 0 ? 1 : 0)), dim3(256), 0, e.stream, ctl, S, ld,
                            n_pad, n_blk, k, n_panel, e.P2[k & 1],
                            k > 0 ? (const double*)e.P2[(k - 1) & 1] : (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
-                           n_upd);
+                           n_upd, n_upd_wg);
+        if (getenv("VMM_BA_DEBUG")) {
+            const hipError_t le = hipPeekAtLastError();
+            if (le != hipSuccess)
+                fprintf(stderr, "[vmm_ba debug] k_chol_step k=%d grid=%d: %s\n", k, n_panel + n_upd_wg + (k > 0 ? 1 : 0),
+                        hipGetErrorString(le));
+        }
     }
     // one chained launch while every workgroup of the chain can be resident; the per-block kernels otherwise
     if (n_blk <= 200 && e.flags && !e.no_chain) {

@@ -252,6 +252,13 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
 {
     if (e.multi || !e.use_graph)
         return enqueue_iteration(e, o);
+    if (!e.launched_eagerly) {
+        // the first iteration of a handle runs eagerly: first launches may load code objects or size
+        // per-kernel resources, which is not allowed inside a stream capture (seen as an intermittent
+        // "operation failed due to a previous error during capture" on the 2000 x 1000 problem)
+        e.launched_eagerly = true;
+        return enqueue_iteration(e, o);
+    }
     if (!e.iter_graph || e.graph_robustify != o.robustify || e.graph_huber_a != o.huber_a) {
         if (e.iter_graph) {
             (void)hipGraphExecDestroy(e.iter_graph);
@@ -401,6 +408,11 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         e.stream = nullptr;
         return fail(VMM_BA_ERR_HIP);
     }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, e.device) == hipSuccess && prop.multiProcessorCount > 0)
+            e.n_cu = prop.multiProcessorCount;
+    }
     e.rank = co.rank;
     e.world = co.world_size;
     e.multi = e.world > 1;
@@ -480,7 +492,10 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.n_red = 6 * e.n_f;
     e.n_pad = round_up(e.n_red, kNB);
     e.n_blk = e.n_pad / kNB;
-    e.ldz = round_up(e.n_pad + 1, kST);   // >= n_pad + 64; the rank-k update reads whole 128-wide tiles
+    // >= n_pad + 64; the rank-k update reads whole 128-wide tiles.  The extra 32 doubles (256 B) make the row
+    // stride an odd multiple of 256 B, so the 64 rows of a tile spread over the HBM channels instead of
+    // hitting a few of them (a 48 KB stride at 2000 x 1000 does)
+    e.ldz = round_up(e.n_pad + 1, kST) + 32;
     e.k_dim = 6 * e.n_e;
     e.k_pad = round_up(e.k_dim, kKT);
     if ((rc = dev_alloc(e, &e.Le, (size_t)36 * e.n_e))) return fail(rc);
@@ -861,6 +876,11 @@ static int make_scratch(Engine& e, int device, int ld)
     e.device = device;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            e.n_cu = prop.multiProcessorCount;
+    }
     int rc;
     if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * ld))) return rc;
     if ((rc = setup_lookahead(e, ld / kNB, ld))) return rc;
