@@ -433,15 +433,14 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
         // touched after the matching s_waitcnt below, which takes them as read-write operands.
         USTAMP(40);
         double creg[2][2][4];
+        const double* pc[16];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double* src = S + (int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi;
-                    __asm__ volatile("global_load_dwordx2 %0, %1, off" : "=&v"(creg[a][b][r]) : "v"(src) : "memory");
-                }
+                for (int r = 0; r < 4; ++r)
+                    pc[8 * a + 4 * b + r] = S + (int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi;
         const bool more = t + n_wg < n_tiles;   // workgroup-uniform
         // next tile = n_wg positions further in the row-major list of lower tiles (rows only get longer, so
         // this is a couple of steps; a search from the first row costs ~50 cycles per row: 2 us at 94 rows).
@@ -458,14 +457,14 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
             nbj = k + 2 + off;
         }
         double2v va[8], vb[8];
+        const double* pa[8];
+        const double* pb[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int idx = it * 256 + tid;
             const int m = idx >> 5, c = (idx & 31) * 2;
-            const double* pa = P + (int64_t)m * ld + nbi * kNB + c;
-            const double* pb = P + (int64_t)m * ld + nbj * kNB + c;
-            __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[it]) : "v"(pa) : "memory");
-            __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[it]) : "v"(pb) : "memory");
+            pa[it] = P + (int64_t)m * ld + nbi * kNB + c;
+            pb[it] = P + (int64_t)m * ld + nbj * kNB + c;
         }
         USTAMP(41);
         double4_t acc[2][2];
@@ -474,17 +473,37 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
 #pragma unroll
             for (int b = 0; b < 2; ++b)
                 acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+        // 16 k-steps; the LDS operands of step ks+1 are read before the MFMAs of step ks, and one of the 16
+        // operand requests of the next tile is issued per step (VMEM issue slots beside the MFMAs)
+        double a0 = -As[fk * kLdsRow + wi * 32 + fi], a1 = -As[fk * kLdsRow + wi * 32 + 16 + fi];
+        double b0 = Bs[fk * kLdsRow + wj * 32 + fi], b1 = Bs[fk * kLdsRow + wj * 32 + 16 + fi];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const int row = (ks * 4 + fk) * kLdsRow;
-            const double a0 = -As[row + wi * 32 + fi];
-            const double a1 = -As[row + wi * 32 + 16 + fi];
-            const double b0 = Bs[row + wj * 32 + fi];
-            const double b1 = Bs[row + wj * 32 + 16 + fi];
+            if (ks < 8) {   // this tile's C values (HBM, the longer latency) first ...
+                __asm__ volatile("global_load_dwordx2 %0, %1, off"
+                                 : "=&v"(creg[(2 * ks) >> 3][((2 * ks) >> 2) & 1][(2 * ks) & 3]) : "v"(pc[2 * ks]) : "memory");
+                __asm__ volatile("global_load_dwordx2 %0, %1, off"
+                                 : "=&v"(creg[(2 * ks + 1) >> 3][((2 * ks + 1) >> 2) & 1][(2 * ks + 1) & 3]) : "v"(pc[2 * ks + 1]) : "memory");
+            } else {        // ... then the next tile's operands (L2)
+                __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[ks - 8]) : "v"(pa[ks - 8]) : "memory");
+                __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[ks - 8]) : "v"(pb[ks - 8]) : "memory");
+            }
+            double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
+            if (ks < 15) {
+                const int row = ((ks + 1) * 4 + fk) * kLdsRow;
+                na0 = -As[row + wi * 32 + fi];
+                na1 = -As[row + wi * 32 + 16 + fi];
+                nb0 = Bs[row + wj * 32 + fi];
+                nb1 = Bs[row + wj * 32 + 16 + fi];
+            }
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = na0;
+            a1 = na1;
+            b0 = nb0;
+            b1 = nb1;
         }
 #ifdef VMM_STAMPS
         __asm__ volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]) : "memory");
