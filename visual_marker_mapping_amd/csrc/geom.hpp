@@ -170,4 +170,30 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Sums 32 per-lane values over the wave with ONE butterfly for all of them: at every level a lane keeps
+// half of its values and sends the other half to its partner (lane ^ offset), so the number of live
+// values halves while the span doubles -- 31 exchanges instead of 32 x 6.  Returns the total of value
+// wave_sum32_index(lane); lanes 2m and 2m+1 hold the same value.  Fixed tree: deterministic.
+__device__ __forceinline__ double wave_sum32(double (&v)[32], const int lane)
+{
+#pragma unroll
+    for (int level = 0; level < 5; ++level) {
+        const int off = 32 >> level;
+        const bool hi = (lane & off) != 0;
+#pragma unroll
+        for (int j = 0; j < (16 >> level); ++j) {
+            const double keep = hi ? v[2 * j + 1] : v[2 * j];
+            const double send = hi ? v[2 * j] : v[2 * j + 1];
+            v[j] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+    return v[0] + __shfl_xor(v[0], 1, 64);
+}
+
+__device__ __forceinline__ int wave_sum32_index(const int lane)
+{
+    return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3)
+        | (((lane >> 1) & 1) << 4);
+}
+
 } // namespace vmm

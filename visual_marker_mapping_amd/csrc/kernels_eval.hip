@@ -124,24 +124,22 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
         for (int k = 0; k < 36; ++k)
             a.W[(int64_t)k * a.n_pad + i] = Wacc[k];
     }
-    // wave reduction of the 28 family sums; lane k keeps value k
-    double mine = 0.0;
+    // wave reduction of the 28 family sums (21 H + 6 g + cost) in one shared butterfly
+    double red[32];
 #pragma unroll
-    for (int k = 0; k < 21; ++k) {
-        const double s = wave_sum(H[k]);
-        mine = (lane == k) ? s : mine;
-    }
+    for (int k = 0; k < 21; ++k)
+        red[k] = H[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double s = wave_sum(g[k]);
-        mine = (lane == 21 + k) ? s : mine;
-    }
-    {
-        const double s = wave_sum(cost);
-        mine = (lane == 27) ? s : mine;
-    }
-    if (lane < 28)
-        a.part[(int64_t)wave * kPart + lane] = mine;
+    for (int k = 0; k < 6; ++k)
+        red[21 + k] = g[k];
+    red[27] = cost;
+#pragma unroll
+    for (int k = 28; k < 32; ++k)
+        red[k] = 0.0;
+    const double mine = wave_sum32(red, lane);
+    const int slot = wave_sum32_index(lane);
+    if (!(lane & 1) && slot < 28)
+        a.part[(int64_t)wave * kPart + slot] = mine;
 }
 
 template <bool OWN_IS_CAM, bool WRITE_W>
@@ -159,7 +157,7 @@ __global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
 // Both family passes in one launch: workgroups [0, nb_e) run the pass over the eliminated family (writes W),
 // the rest the pass over the kept family.  The passes are independent, so they share the chip.
 template <bool E_IS_CAM>
-__global__ __launch_bounds__(256) void k_eval_both(const EvalArgs aE, const EvalArgs aF, const int nb_e)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_eval_both(const EvalArgs aE, const EvalArgs aF, const int nb_e)
 {
     if (aE.ctl) {
         if (aE.ctl->done)
