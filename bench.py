@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--poll", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--elimination", choices=["auto", "cams", "tags"], default="auto")
+    ap.add_argument("--precision", choices=["f64", "f32"], default=None,
+                    help="f32 = J^T J blocks accumulated/stored in f32, everything else f64 (default for --config 4, "
+                         "as BASELINE.json configs[3] words it); f64 otherwise")
     return ap.parse_args()
 
 
@@ -93,10 +96,12 @@ def main():
     elim = {"auto": eng.ELIM_AUTO, "cams": eng.ELIM_CAMERAS, "tags": eng.ELIM_TAGS}[a.elimination]
     elim_cams = None if a.elimination == "auto" else (a.elimination == "cams")
     idx, elim_cams = vdist.shard_observations(s.obs_cam, s.obs_tag, n_cams, n_tags, rank, world, elim_cams)
+    precision = a.precision or ("f32" if a.config == 4 else "f64")
     t0 = time.time()
     ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam[idx],
                             s.obs_tag[idx], s.obs_px[idx], device=local_rank, elimination=elim, rank=rank,
-                            world_size=world)
+                            world_size=world,
+                            precision=eng.PRECISION_F32_ACCUM if precision == "f32" else eng.PRECISION_F64)
     setup_s = time.time() - t0
     if use_dist:
         ba.set_allreduce(vdist.make_allreduce(local_rank))
@@ -130,7 +135,8 @@ def main():
         line = {
             "metric": "lm_iterations_per_sec", "value": it_per_s, "unit": "LM iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if precision == "f64" else "f32 J^T J accumulation, f64 residuals/gradient/reduced system/solve",
             "data": "synthetic",
             "config": {"workload": "configs[%d]: %d images x %d tags, visibility %.2f, %d tag observations "
                                    "(%d corner residual blocks), %s, perturbed initial guess"
@@ -153,7 +159,8 @@ def main():
             # algorithmic bytes per tag observation: SURVEY.md 8(d) -- 360 B for the fused
             # residual+Jacobian+accumulate evaluation (72 B in + one f64 6x6 W block out), 72 B cost-only
             "eval_jacobian": {"ms": kt["eval_elim_ms"] + kt["eval_keep_ms"], "bound": "hbm",
-                              "alg": 360.0 * n_obs, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+                              "alg": (360.0 if precision == "f64" else 216.0) * n_obs, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s"},
             "eval_cost": {"ms": kt["cost_ms"], "bound": "hbm", "alg": 72.0 * n_obs, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s"},
             # S = Z^T Z, lower triangle incl. the rhs row: (n+1)(n+2)/2 * K multiply-adds

@@ -71,6 +71,9 @@ typedef struct vmm_ba_problem {
     const double* obs_px;    /* [8*n_obs] (src/DetectionIO.cpp:45-51) */
 } vmm_ba_problem;
 
+#define VMM_BA_PRECISION_F64 0
+#define VMM_BA_PRECISION_F32_ACCUM 1
+
 typedef struct vmm_ba_create_options {
     int32_t device;          /* HIP device ordinal */
     int32_t elimination;     /* VMM_BA_ELIM_* */
@@ -79,6 +82,12 @@ typedef struct vmm_ba_create_options {
      * informational, the exchange itself goes through vmm_ba_set_allreduce(). */
     int32_t rank;
     int32_t world_size;
+    /* VMM_BA_PRECISION_F64 (default): everything in f64, as the reference.
+     * VMM_BA_PRECISION_F32_ACCUM (BASELINE.json configs[3]): the Gauss-Newton blocks J^T J (per-pose 6x6
+     * and per-observation J_e^T J_f) are accumulated and stored in f32; residuals, cost, the gradient
+     * J^T r, the reduced system S, its factorisation and every LM decision stay f64.  The fixed point
+     * (zero gradient) is unchanged, the LM trajectory is that of a slightly perturbed Gauss-Newton model. */
+    int32_t precision;
 } vmm_ba_create_options;
 
 /* Solver::Options fields the reference sets (src/TagReconstructor.cpp:725-735) plus the Ceres

@@ -186,3 +186,42 @@ def test_tag_translation_covariance_matches_oracle(oracle, elim, robust):
         assert scale > 0
         np.testing.assert_allclose(cov[t], ref[t], rtol=0, atol=1e-6 * scale)
         assert np.all(np.linalg.eigvalsh(cov[t]) > 0)
+
+
+@pytest.mark.parametrize("config", [1, 5])
+def test_f32_accumulate_precision_reaches_the_f64_optimum(oracle, config):
+    """VMM_BA_PRECISION_F32_ACCUM (BASELINE.json configs[3]): J^T J blocks in f32, residuals / gradient /
+    reduced system / LM decisions in f64.  The blocks match the oracle to f32 rounding and the solve ends at
+    the f64 optimum: cost to 1e-8 relative, poses to 1e-5 of the pose scale (both runs stop on the same
+    1e-6 relative-cost-change test, somewhere inside that distance of the minimiser)."""
+    from visual_marker_mapping_amd import engine
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(config, n_cams=40, n_tags=16)
+    robust = config == 5
+    res = {}
+    for name, prec in (("f64", engine.PRECISION_F64), ("f32", engine.PRECISION_F32_ACCUM)):
+        ba = engine.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px,
+                                   precision=prec)
+        try:
+            blocks = ba.eval_blocks(robustify=robust)
+            summ = ba.solve(engine.default_options(robustify=int(robust)))
+            cam, tag = ba.get_state()
+            cost = ba.cost(robustify=robust)
+        finally:
+            ba.close()
+        res[name] = (blocks, summ, cam, tag, cost)
+    b64, b32 = res["f64"][0], res["f32"][0]
+    for key in ("V", "U", "W"):
+        scale = np.abs(b64[key]).max()
+        assert np.abs(b32[key] - b64[key]).max() < 2e-5 * scale          # f32 products summed over <= 64 x 8 rows
+        assert np.abs(b32[key] - b64[key]).max() > 0                      # and it really is a different precision
+    np.testing.assert_allclose(b32["g_cam"], b64["g_cam"], rtol=0, atol=1e-12 * np.abs(b64["g_cam"]).max())   # f64 both
+    assert b32["cost"] == b64["cost"]
+    assert res["f32"][1]["termination_type"] == engine.CONVERGENCE
+    assert abs(res["f32"][4] - res["f64"][4]) <= 1e-8 * res["f64"][4]
+    for k in (2, 3):
+        scale = np.abs(res["f64"][k]).max()
+        assert np.abs(res["f32"][k] - res["f64"][k]).max() < 1e-5 * scale
+    with pytest.raises(Exception):
+        engine.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px,
+                              precision=7)

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VMM_BA_LIB selects another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("VMM_BA_LIB") or os.path.join(_HERE, "libvmm_ba.so")
 
+PRECISION_F64, PRECISION_F32_ACCUM = 0, 1
 OK, ERR_ARGUMENT, ERR_HIP, ERR_COLLECTIVE, ERR_STATE, ERR_NUMERIC = 0, 1, 2, 3, 4, 5
 ELIM_AUTO, ELIM_TAGS, ELIM_CAMERAS = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
@@ -31,7 +32,7 @@ class Problem(C.Structure):
 
 class CreateOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("elimination", C.c_int32), ("rank", C.c_int32),
-                ("world_size", C.c_int32)]
+                ("world_size", C.c_int32), ("precision", C.c_int32)]
 
 
 class Options(C.Structure):

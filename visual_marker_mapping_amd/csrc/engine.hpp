@@ -103,7 +103,9 @@ struct Engine {
     // all-reduced first when world > 1)
     double* small_stage = nullptr;
     double *ev_H_cam = nullptr, *ev_H_tag = nullptr, *ev_g_cam = nullptr, *ev_g_tag = nullptr, *ev_cost = nullptr;
-    double* W = nullptr;            // [36][ordE.n_pad]: J_e^T J_f per observation, E order
+    double* W = nullptr;            // [36][ordE.n_pad]: J_e^T J_f per observation, E order (f64 precision)
+    float* Wf = nullptr;            // the same in f32 (VMM_BA_PRECISION_F32_ACCUM); exactly one of the two exists
+    bool f32_accum = false;
 
     // tangent-space vectors, cameras first then tags (6 each)
     double *scale = nullptr, *diag = nullptr, *D2 = nullptr, *delta = nullptr;

@@ -30,14 +30,16 @@ struct EvalArgs {
     int robustify;
     double huber_a;
     double* part;              // [n_tasks][kPart]
-    double* W;                 // [36][n_pad] or null
+    void* W;                   // [36][n_pad] of AT (double or float) or null
     const LmCtl* ctl;          // null: always run
     int guard_need_jacobian;
 };
 
 __device__ __forceinline__ int tri(int a, int b) { return a * (a + 1) / 2 + b; }
 
-template <bool OWN_IS_CAM, bool WRITE_W>
+// AT: accumulation/storage type of the J^T J blocks (double, or float for VMM_BA_PRECISION_F32_ACCUM);
+// residuals, the cost and the gradient J^T r are always f64.
+template <bool OWN_IS_CAM, bool WRITE_W, typename AT>
 __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
 {
     const int lane = threadIdx.x & 63;
@@ -60,18 +62,19 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
     const double tag_on = (tag_idx == a.fixed_tag) ? 0.0 : 1.0;
     const double mask = valid ? 1.0 : 0.0;
 
-    double H[21], g[6], cost = 0.0;
-    double Wacc[WRITE_W ? 36 : 1];
+    AT H[21];
+    double g[6], cost = 0.0;
+    AT Wacc[WRITE_W ? 36 : 1];
 #pragma unroll
     for (int k = 0; k < 21; ++k)
-        H[k] = 0.0;
+        H[k] = (AT)0;
 #pragma unroll
     for (int k = 0; k < 6; ++k)
         g[k] = 0.0;
     if (WRITE_W) {
 #pragma unroll
         for (int k = 0; k < 36; ++k)
-            Wacc[k] = 0.0;
+            Wacc[k] = (AT)0;
     }
 
     constexpr bool NEED_JC = OWN_IS_CAM || WRITE_W;
@@ -99,36 +102,40 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
 #pragma unroll
             for (int k = 0; k < 6; ++k)
                 jo[k] = (OWN_IS_CAM ? e.jc[r][k] : e.jt[r][k]) * w_own;
+            AT ja[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                ja[k] = (AT)jo[k];
 #pragma unroll
             for (int p = 0; p < 6; ++p) {
                 g[p] += jo[p] * res;
 #pragma unroll
                 for (int q = 0; q <= p; ++q)
-                    H[tri(p, q)] += jo[p] * jo[q];
+                    H[tri(p, q)] += ja[p] * ja[q];
             }
             if (WRITE_W) {
-                double jx[6];
+                AT jx[6];
 #pragma unroll
                 for (int k = 0; k < 6; ++k)
-                    jx[k] = (OWN_IS_CAM ? e.jt[r][k] : e.jc[r][k]) * w_oth;
+                    jx[k] = (AT)((OWN_IS_CAM ? e.jt[r][k] : e.jc[r][k]) * w_oth);
 #pragma unroll
                 for (int p = 0; p < 6; ++p)
 #pragma unroll
                     for (int q = 0; q < 6; ++q)
-                        Wacc[6 * p + q] += jo[p] * jx[q];
+                        Wacc[6 * p + q] += ja[p] * jx[q];
             }
         }
     }
     if (WRITE_W && valid) {
 #pragma unroll
         for (int k = 0; k < 36; ++k)
-            a.W[(int64_t)k * a.n_pad + i] = Wacc[k];
+            static_cast<AT*>(a.W)[(int64_t)k * a.n_pad + i] = Wacc[k];
     }
     // wave reduction of the 28 family sums (21 H + 6 g + cost) in one shared butterfly
     double red[32];
 #pragma unroll
     for (int k = 0; k < 21; ++k)
-        red[k] = H[k];
+        red[k] = (double)H[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
         red[21 + k] = g[k];
@@ -142,7 +149,7 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
         a.part[(int64_t)wave * kPart + slot] = mine;
 }
 
-template <bool OWN_IS_CAM, bool WRITE_W>
+template <bool OWN_IS_CAM, bool WRITE_W, typename AT = double>
 __global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
 {
     if (a.ctl) {
@@ -151,12 +158,12 @@ __global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
         if (a.guard_need_jacobian && !a.ctl->need_jacobian)
             return;
     }
-    eval_body<OWN_IS_CAM, WRITE_W>(a, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    eval_body<OWN_IS_CAM, WRITE_W, AT>(a, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
 }
 
 // Both family passes in one launch: workgroups [0, nb_e) run the pass over the eliminated family (writes W),
 // the rest the pass over the kept family.  The passes are independent, so they share the chip.
-template <bool E_IS_CAM>
+template <bool E_IS_CAM, typename AT = double>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_eval_both(const EvalArgs aE, const EvalArgs aF, const int nb_e)
 {
     if (aE.ctl) {
@@ -166,9 +173,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             return;
     }
     if ((int)blockIdx.x < nb_e)
-        eval_body<E_IS_CAM, true>(aE, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+        eval_body<E_IS_CAM, true, AT>(aE, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     else
-        eval_body<!E_IS_CAM, false>(aF, (int)(((blockIdx.x - nb_e) * blockDim.x + threadIdx.x) >> 6));
+        eval_body<!E_IS_CAM, false, AT>(aF, (int)(((blockIdx.x - nb_e) * blockDim.x + threadIdx.x) >> 6));
 }
 
 // Sums the task partials of every pose in task order and expands the packed lower triangle.
@@ -380,7 +387,7 @@ __global__ void k_project(Intrinsics K, int64_t n, const double* __restrict__ pc
 
 static inline int blocks_for_tasks(int n_tasks) { return (n_tasks + 3) / 4; }
 
-static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, double* W, bool guard)
+static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, void* W, bool guard)
 {
     EvalArgs a;
     a.K = e.K;
@@ -406,7 +413,7 @@ void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, do
 {
     const bool e_is_cam = e.elim_cams;
     const bool own_is_cam = elim_family ? e_is_cam : !e_is_cam;
-    EvalArgs a = make_eval_args(e, elim_family ? e.ordE : e.ordF, own_is_cam, elim_family ? e.W : nullptr, guard);
+    EvalArgs a = make_eval_args(e, elim_family ? e.ordE : e.ordF, own_is_cam, elim_family ? (e.f32_accum ? (void*)e.Wf : (void*)e.W) : nullptr, guard);
     a.robustify = robustify;
     a.huber_a = huber_a;
     if (!use_ctl)
@@ -414,7 +421,19 @@ void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, do
     if (a.n_tasks <= 0)
         return;
     const dim3 grid(blocks_for_tasks(a.n_tasks)), block(256);
-    if (elim_family) {
+    if (e.f32_accum) {
+        if (elim_family) {
+            if (own_is_cam)
+                hipLaunchKernelGGL((k_eval<true, true, float>), grid, block, 0, e.stream, a);
+            else
+                hipLaunchKernelGGL((k_eval<false, true, float>), grid, block, 0, e.stream, a);
+        } else {
+            if (own_is_cam)
+                hipLaunchKernelGGL((k_eval<true, false, float>), grid, block, 0, e.stream, a);
+            else
+                hipLaunchKernelGGL((k_eval<false, false, float>), grid, block, 0, e.stream, a);
+        }
+    } else if (elim_family) {
         if (own_is_cam)
             hipLaunchKernelGGL((k_eval<true, true>), grid, block, 0, e.stream, a);
         else
@@ -431,7 +450,7 @@ void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, do
 void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bool use_ctl)
 {
     const bool e_is_cam = e.elim_cams;
-    EvalArgs aE = make_eval_args(e, e.ordE, e_is_cam, e.W, guard);
+    EvalArgs aE = make_eval_args(e, e.ordE, e_is_cam, e.f32_accum ? (void*)e.Wf : (void*)e.W, guard);
     EvalArgs aF = make_eval_args(e, e.ordF, !e_is_cam, nullptr, guard);
     aE.robustify = aF.robustify = robustify;
     aE.huber_a = aF.huber_a = huber_a;
@@ -439,7 +458,12 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
         aE.ctl = aF.ctl = nullptr;
     const int nb_e = blocks_for_tasks(aE.n_tasks), nb_f = blocks_for_tasks(aF.n_tasks);
     if (nb_e + nb_f > 0) {
-        if (e_is_cam)
+        if (e.f32_accum) {
+            if (e_is_cam)
+                hipLaunchKernelGGL((k_eval_both<true, float>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
+            else
+                hipLaunchKernelGGL((k_eval_both<false, float>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
+        } else if (e_is_cam)
             hipLaunchKernelGGL((k_eval_both<true>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
         else
             hipLaunchKernelGGL((k_eval_both<false>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);

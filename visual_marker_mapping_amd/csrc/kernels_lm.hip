@@ -253,10 +253,11 @@ __global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, co
 // Back-substitution of the eliminated family: y_e = L_e^{-T} (z_e - Z_e y_f), delta_e = -s_e y_e, and
 // the pose's share of the model-cost cross term sum_obs delta_e^T W_ef delta_f.  One wave per
 // eliminated pose (its observations are contiguous in E order).
+template <typename WT>
 __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose, int f_off_pose,
                                                  const int32_t* __restrict__ pose_task,
                                                  const Task* __restrict__ tasks, const int32_t* __restrict__ other,
-                                                 const double* __restrict__ W, int64_t n_pad_obs,
+                                                 const WT* __restrict__ W, int64_t n_pad_obs,
                                                  const double* __restrict__ Z, int ldz, int n_red,
                                                  const double* __restrict__ yf, const double* __restrict__ Le,
                                                  const double* __restrict__ ze, const double* __restrict__ scale,
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
                 double r = 0.0;
 #pragma unroll
                 for (int b = 0; b < 6; ++b)
-                    r += W[(int64_t)(6 * a + b) * n_pad_obs + i] * df[b];
+                    r += (double)W[(int64_t)(6 * a + b) * n_pad_obs + i] * df[b];
                 cr += de[a] * r;
             }
         }
@@ -557,9 +558,14 @@ void launch_backsub(Engine& e)
 {
     const int e_off = e.elim_cams ? 0 : e.n_cams;
     const int f_off = e.elim_cams ? e.n_cams : 0;
-    hipLaunchKernelGGL(k_backsub, dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, f_off,
-                       e.ordE.pose_task, e.ordE.tasks, e.ordE.other, e.W, e.ordE.n_pad, e.Z, e.ldz, e.n_red, e.yf,
-                       e.Le, e.ze, e.scale, e.step_comm, e.part_cross);
+    if (e.f32_accum)
+        hipLaunchKernelGGL((k_backsub<float>), dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, f_off,
+                           e.ordE.pose_task, e.ordE.tasks, e.ordE.other, (const float*)e.Wf, e.ordE.n_pad, e.Z, e.ldz,
+                           e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross);
+    else
+        hipLaunchKernelGGL((k_backsub<double>), dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, f_off,
+                           e.ordE.pose_task, e.ordE.tasks, e.ordE.other, (const double*)e.W, e.ordE.n_pad, e.Z, e.ldz,
+                           e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross);
 }
 
 void launch_candidate(Engine& e)

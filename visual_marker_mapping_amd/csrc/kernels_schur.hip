@@ -92,10 +92,11 @@ __global__ void k_elim_factor(LmCtl* ctl, int n_e, int e_off_pose, const double*
 }
 
 // One thread per observation (E order): Z block = L_e^{-1} (s_e W s_f) into the dense Z.
+template <typename WT>
 __global__ __launch_bounds__(256) void k_form_z(const LmCtl* ctl, int64_t n_obs, int64_t n_pad,
                                                  const int32_t* __restrict__ own,
                                                  const int32_t* __restrict__ other,
-                                                 const double* __restrict__ W,
+                                                 const WT* __restrict__ W,
                                                  const double* __restrict__ Le,
                                                  const double* __restrict__ scale, int e_off_pose,
                                                  int f_off_pose, double* __restrict__ Z, int ldz)
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_form_z(const LmCtl* ctl, int64_t n_obs,
     for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b = 0; b < 6; ++b)
-            X[6 * a + b] = se[a] * W[(int64_t)(6 * a + b) * n_pad + i] * sf[b];
+            X[6 * a + b] = se[a] * (double)W[(int64_t)(6 * a + b) * n_pad + i] * sf[b];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         const double inv = 1.0 / L[6 * r + r];
@@ -378,10 +379,15 @@ void launch_elim(Engine& e)
     const double* g_E = e.elim_cams ? e.g_cam : e.g_tag;
     hipLaunchKernelGGL(k_elim_factor, dim3((e.n_e + 63) / 64), dim3(64), 0, e.stream, e.ctl, e.n_e, e_off, H_E, g_E,
                        e.scale, e.D2, e.Le, e.ze, e.ordE.pose_task, e.Z, e.ldz, e.n_pad);
-    if (e.ordE.n > 0)
-        hipLaunchKernelGGL(k_form_z, dim3((unsigned)((e.ordE.n + 255) / 256)), dim3(256), 0, e.stream, e.ctl,
-                           e.ordE.n, e.ordE.n_pad, e.ordE.own, e.ordE.other, e.W, e.Le, e.scale, e_off, f_off,
-                           e.Z, e.ldz);
+    if (e.ordE.n > 0) {
+        const dim3 grid((unsigned)((e.ordE.n + 255) / 256));
+        if (e.f32_accum)
+            hipLaunchKernelGGL((k_form_z<float>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,
+                               e.ordE.other, (const float*)e.Wf, e.Le, e.scale, e_off, f_off, e.Z, e.ldz);
+        else
+            hipLaunchKernelGGL((k_form_z<double>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,
+                               e.ordE.other, (const double*)e.W, e.Le, e.scale, e_off, f_off, e.Z, e.ldz);
+    }
 }
 
 void launch_syrk_plan(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, const SyrkPlan& p)

@@ -382,6 +382,10 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         set_error("fixed_tag out of range");
         return VMM_BA_ERR_ARGUMENT;
     }
+    if (co.precision != VMM_BA_PRECISION_F64 && co.precision != VMM_BA_PRECISION_F32_ACCUM) {
+        set_error("create_options.precision must be VMM_BA_PRECISION_F64 or VMM_BA_PRECISION_F32_ACCUM");
+        return VMM_BA_ERR_ARGUMENT;
+    }
     if (co.world_size < 1 || co.rank < 0 || co.rank >= co.world_size) {
         set_error("bad rank / world_size");
         return VMM_BA_ERR_ARGUMENT;
@@ -415,6 +419,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     }
     e.rank = co.rank;
     e.world = co.world_size;
+    e.f32_accum = co.precision == VMM_BA_PRECISION_F32_ACCUM;
     e.multi = e.world > 1;
     if (const char* fw = getenv("VMM_BA_FORCE_COLLECTIVES"))
         if (fw[0] == '1')
@@ -481,7 +486,9 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.ev_g_cam = e.ev_H_tag + (size_t)36 * e.n_tags;
     e.ev_g_tag = e.ev_g_cam + (size_t)6 * e.n_cams;
     e.ev_cost = e.ev_g_tag + (size_t)6 * e.n_tags;
-    if ((rc = dev_alloc(e, &e.W, (size_t)36 * e.ordE.n_pad))) return fail(rc);
+    if (e.f32_accum) {
+        if ((rc = dev_alloc(e, &e.Wf, (size_t)36 * e.ordE.n_pad))) return fail(rc);
+    } else if ((rc = dev_alloc(e, &e.W, (size_t)36 * e.ordE.n_pad))) return fail(rc);
     if ((rc = dev_alloc(e, &e.scale, (size_t)6 * n_pose))) return fail(rc);
     if ((rc = dev_alloc(e, &e.diag, (size_t)6 * n_pose))) return fail(rc);
     if ((rc = dev_alloc(e, &e.D2, (size_t)6 * n_pose))) return fail(rc);
@@ -856,7 +863,14 @@ int vmm_ba_eval_blocks(vmm_ba_handle h, int robustify, double huber_a, double* c
     if (W && e.n_obs > 0) {
         std::vector<double> w((size_t)36 * e.ordE.n_pad);
         std::vector<int32_t> caller((size_t)e.n_obs);
-        HIP_TRY(hipMemcpy(w.data(), e.W, sizeof(double) * w.size(), hipMemcpyDeviceToHost));
+        if (e.f32_accum) {
+            std::vector<float> wf(w.size());
+            HIP_TRY(hipMemcpy(wf.data(), e.Wf, sizeof(float) * wf.size(), hipMemcpyDeviceToHost));
+            for (size_t q = 0; q < w.size(); ++q)
+                w[q] = (double)wf[q];
+        } else {
+            HIP_TRY(hipMemcpy(w.data(), e.W, sizeof(double) * w.size(), hipMemcpyDeviceToHost));
+        }
         HIP_TRY(hipMemcpy(caller.data(), e.ordE.caller, sizeof(int32_t) * caller.size(), hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < e.n_obs; ++i)
             for (int a = 0; a < 6; ++a)

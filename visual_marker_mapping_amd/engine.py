@@ -8,7 +8,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (CONVERGENCE, ELIM_AUTO, ELIM_CAMERAS, ELIM_TAGS, FAILURE, NO_CONVERGENCE)  # noqa: F401
+from ._lib import (CONVERGENCE, ELIM_AUTO, ELIM_CAMERAS, ELIM_TAGS, FAILURE, NO_CONVERGENCE,  # noqa: F401
+                   PRECISION_F32_ACCUM, PRECISION_F64)
 
 
 def _ptr(a):
@@ -27,7 +28,7 @@ def default_options(**kw):
 
 class BundleAdjuster:
     def __init__(self, intr, dist, cam_qt, tag_qt, tag_wh, fixed_tag, obs_cam, obs_tag, obs_px,
-                 device=0, elimination=ELIM_AUTO, rank=0, world_size=1):
+                 device=0, elimination=ELIM_AUTO, rank=0, world_size=1, precision=PRECISION_F64):
         L = _lib.lib()
         self._h = C.c_void_p()
         self.intr = np.ascontiguousarray(intr, np.float64).reshape(4)
@@ -55,6 +56,7 @@ class BundleAdjuster:
         co = _lib.CreateOptions()
         L.vmm_ba_default_create_options(C.byref(co))
         co.device, co.elimination, co.rank, co.world_size = device, elimination, rank, world_size
+        co.precision = int(precision)
         _lib.check(L.vmm_ba_create(C.byref(p), C.byref(co), C.byref(self._h)))
         self._allreduce_cb = None
 
