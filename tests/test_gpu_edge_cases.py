@@ -1,0 +1,87 @@
+"""GPU parity on degenerate / ragged problems (the shapes startReconstruction produces on its way up):
+one camera and one tag, poses without observations in the middle of the arrays, no constant block at all,
+more tags than cameras, a zero-iteration budget, and empty observation lists.  Oracle = oracle/ (CPU)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-6
+
+
+def _solve_both(s, oracle, cam0, tag0, fixed, oc, ot, px, wh, **opt):
+    from visual_marker_mapping_amd import engine as eng
+    ba = eng.BundleAdjuster(s.intr, s.dist, cam0, tag0, wh, fixed, oc, ot, px)
+    out = ba.solve(eng.default_options(**opt))
+    cam, tag = ba.get_state()
+    pc, pt, avg, _ = ba.reprojection_stats()
+    ba.close()
+    sc = oracle.Scene(s.intr, s.dist, cam0, tag0, wh, fixed, oc, ot, px)
+    summ, _ = oracle.solve(sc, oracle.default_options(linear_solver=oracle.DENSE_NORMAL, **opt))
+    opc, opt_, oavg, _ = oracle.reprojection_stats(sc)
+    assert out["termination_type"] == summ["termination_type"] and out["iterations"] == summ["iterations"]
+    scale = max(np.abs(sc.cam_qt).max(), np.abs(sc.tag_qt).max())
+    np.testing.assert_allclose(cam, sc.cam_qt, rtol=0, atol=REL * scale)
+    np.testing.assert_allclose(tag, sc.tag_qt, rtol=0, atol=REL * scale)
+    np.testing.assert_allclose(pc, opc, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(pt, opt_, rtol=1e-6, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(avg, oavg, rtol=1e-6)
+    return out, cam, tag, pc, pt
+
+
+def test_one_camera_one_fixed_tag(oracle):
+    """The first image of startReconstruction: only the camera moves; the tag block is constant."""
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=1, n_tags=1)
+    out, cam, tag, _, _ = _solve_both(s, oracle, s.cam_init, s.tag_init, 0, s.obs_cam, s.obs_tag, s.obs_px, s.tag_wh,
+                                      robustify=1)
+    assert np.array_equal(tag, s.tag_init)            # constant block untouched, bit for bit
+    assert out["final_cost"] < out["initial_cost"]
+
+
+def test_poses_without_observations_stay_put(oracle):
+    """Camera 2 and tag 3 lose all their observations: they are not part of the reduced program
+    (src/TagReconstructor.cpp:689-690 never adds such a camera), keep their values, and the statistics report
+    -1.0 for the camera (:379-383) and NaN (no map entry) for the tag."""
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=7, n_tags=6)
+    keep = (s.obs_cam != 2) & (s.obs_tag != 3)
+    out, cam, tag, pc, pt = _solve_both(s, oracle, s.cam_init, s.tag_init, 0, s.obs_cam[keep], s.obs_tag[keep],
+                                        s.obs_px[keep], s.tag_wh, robustify=0)
+    assert np.array_equal(cam[2], s.cam_init[2]) and np.array_equal(tag[3], s.tag_init[3])
+    assert pc[2] == -1.0 and np.isnan(pt[3])
+    assert not np.array_equal(cam[1], s.cam_init[1])
+
+
+def test_no_constant_block(oracle):
+    """fixed_tag = -1: the gauge is free, the normal matrix is singular without damping; LM's diagonal
+    makes every step well defined and both implementations walk the same path."""
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=6, n_tags=5)
+    _solve_both(s, oracle, s.cam_init, s.tag_init, -1, s.obs_cam, s.obs_tag, s.obs_px, s.tag_wh, robustify=0,
+                max_num_iterations=12)
+
+
+def test_more_tags_than_cameras_eliminates_tags(oracle):
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=4, n_tags=23, visibility=0.8)
+    _solve_both(s, oracle, s.cam_init, s.tag_init, 0, s.obs_cam, s.obs_tag, s.obs_px, s.tag_wh, robustify=1)
+
+
+def test_zero_iterations_and_empty_problem(oracle):
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=3, n_tags=3)
+    out, cam, tag, _, _ = _solve_both(s, oracle, s.cam_init, s.tag_init, 0, s.obs_cam, s.obs_tag, s.obs_px, s.tag_wh,
+                                      robustify=0, max_num_iterations=0)
+    assert out["termination_type"] == eng.NO_CONVERGENCE and np.array_equal(cam, s.cam_init)
+    # no observations at all: nothing to optimise, poses untouched, every camera reports -1
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, [], [], np.zeros((0, 8)))
+    try:
+        out = ba.solve(eng.default_options())
+        cam, tag = ba.get_state()
+        pc, pt, avg, corner = ba.reprojection_stats()
+        assert np.all(ba.tag_translation_covariance() == 0.0)
+    finally:
+        ba.close()
+    assert out["termination_type"] == eng.CONVERGENCE and np.array_equal(cam, s.cam_init) and np.array_equal(tag, s.tag_init)
+    assert np.all(pc == -1.0) and np.all(np.isnan(pt)) and corner.shape == (0, 8)
