@@ -11,6 +11,7 @@ path; its two PnP initialisations (OpenCV in the reference) live in pnp.py.  Cal
 initial poses through setReconstructedTags / setReconstructedCameras and call doBundleAdjustment directly.
 """
 import math
+import os
 
 import numpy as np
 
@@ -150,6 +151,7 @@ class TagReconstructor:
         self.device = int(device)
         self.lastSummary = None                                # summary of the last doBundleAdjustment
         self.lastCovariances = None                            # tag id -> 3x3 (last printSummary call)
+        self._cached = None                                    # (structure key, BundleAdjuster) of the last call
 
     # -- trivial accessors (src/TagReconstructor.cpp:75-84, 818-842) --
     def getLowestTag(self):
@@ -341,8 +343,40 @@ class TagReconstructor:
                     obs_px=np.asarray(obs_px, np.float64).reshape(-1, 8))
 
     def _engine_for(self, p, **kw):
-        return _engine.BundleAdjuster(p["intr"], p["dist"], p["cam_qt"], p["tag_qt"], p["tag_wh"], p["fixed"],
-                                      p["obs_cam"], p["obs_tag"], p["obs_px"], device=self.device, **kw)
+        """A device handle for the packed problem.  The handle of the previous call is kept and reused when the
+        problem structure (ids, observations, constants) is unchanged -- the usual case for the statistics that
+        follow every bundle adjustment of the incremental driver -- so only the 7 doubles per pose travel."""
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        for a in (np.asarray(p["cam_ids"], np.int64), np.asarray(p["tag_ids"], np.int64), p["obs_cam"], p["obs_tag"],
+                  p["obs_px"], p["tag_wh"], np.asarray(p["intr"], np.float64), np.asarray(p["dist"], np.float64)):
+            h.update(np.ascontiguousarray(a).tobytes())
+            h.update(b"|")
+        key = (h.hexdigest(), int(p["fixed"]), tuple(sorted(kw.items())))
+        if self._cached is not None and self._cached[0] == key and not os.environ.get("VMM_BA_NO_HANDLE_CACHE"):
+            ba = self._cached[1]
+            ba.set_state(p["cam_qt"], p["tag_qt"])
+            return ba
+        self._drop_cached()
+        ba = _engine.BundleAdjuster(p["intr"], p["dist"], p["cam_qt"], p["tag_qt"], p["tag_wh"], p["fixed"],
+                                    p["obs_cam"], p["obs_tag"], p["obs_px"], device=self.device, **kw)
+        self._cached = (key, ba)
+        return ba
+
+    def _drop_cached(self):
+        if self._cached is not None:
+            self._cached[1].close()
+            self._cached = None
+
+    def close(self):
+        """Releases the cached device handle (also done on garbage collection)."""
+        self._drop_cached()
+
+    def __del__(self):
+        try:
+            self._drop_cached()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
 
     # -- the hot path --
     def doBundleAdjustment(self, maxNumIterations, ceresThreads=1, robustify=True, printSummary=False,
@@ -361,8 +395,9 @@ class TagReconstructor:
             summary = ba.solve(opts, trace_capacity=int(maxNumIterations) + 2 if printSummary else 0)
             cam, tag = ba.get_state()
             cov = ba.tag_translation_covariance(robustify, opts.huber_a) if printSummary else None   # :744-760
-        finally:
-            ba.close()
+        except Exception:
+            self._drop_cached()
+            raise
         for k, cid in enumerate(p["cam_ids"]):
             self.reconstructedCameras[cid].q = cam[k, :4].copy()
             self.reconstructedCameras[cid].t = cam[k, 4:].copy()
@@ -397,11 +432,12 @@ class TagReconstructor:
         p = self._pack(for_ba=False)
         if len(p["cam_ids"]) == 0 or len(p["tag_ids"]) == 0:
             return p, np.zeros(0), np.zeros(0), 0.0, np.zeros((0, 8))
-        ba = self._engine_for(p)
+        ba = self._engine_for(p, elimination=_engine.ELIM_AUTO)
         try:
             pc, pt, avg, corner = ba.reprojection_stats(per_corner=per_corner)
-        finally:
-            ba.close()
+        except Exception:
+            self._drop_cached()
+            raise
         return p, pc, pt, avg, corner
 
     def computeReprojectionErrorPerImg(self):
