@@ -124,7 +124,8 @@ struct Engine {
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
     double* Ldiag = nullptr;        // [n_blk][64][64] Cholesky factors of the diagonal blocks
     double* Linv = nullptr;         // [n_blk][64][64] their inverses (all but the last block)
-    unsigned* flags = nullptr;      // [256] hand-off flags of the chained back-substitution + [1] epoch word
+    unsigned* flags = nullptr;      // [256] unused + [1] epoch word of the chained back-substitution
+    unsigned long long* gran = nullptr;   // [2 * ld] {epoch, 32 value bits} granules of the chain's hand-offs
     bool no_chain = false;          // VMM_BA_NO_CHAIN=1: per-block back-substitution kernels
     double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)
     double* step_comm = nullptr;    // [6*n_e + 2]: delta of the eliminated family | cross term

@@ -628,19 +628,20 @@ __global__ __launch_bounds__(256) void k_backsolve_step(const LmCtl* ctl, double
 }
 
 // Whole back-substitution L^T y = w in ONE launch: workgroup p owns block m = n_blk-1-p and depends on
-// the workgroups before it (dispatched earlier), which publish their 64 unknowns through agent-scope
-// (sc1) stores followed by a flag (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "valid
-// forms": one lane of the storing wave signals after that wave's s_waitcnt vmcnt(0); the consumer polls
-// with sc1 loads from one lane, joins a workgroup barrier, then reads the payload with sc1 loads).
-// While it waits, a workgroup already holds the next L tile in registers, so each hand-off costs the
-// flag latency + a 64x64 GEMV slice; the 19 kernel boundaries of the per-block version disappear.
+// the workgroups before it (dispatched earlier), which publish their 64 unknowns as self-validating
+// granules (cdna_hip_programming.md Guideline 16, R2: "the data IS the flag"): every double travels as two
+// 8-byte {tag = epoch, 32 value bits} words written by ONE aligned agent-scope (sc1) store each; one wave
+// of the consumer re-reads its 128 granules with sc1 loads until every tag carries this solve's epoch and
+// hands the values to the other waves through LDS.  One L2 round trip per hop instead of two (flag, then
+// payload), no drain + flag store on the producer side.  While it waits, a workgroup already holds the
+// next L tile in registers; the 19 kernel boundaries of the per-block version disappear.
 // Every spin is bounded: on a timeout the solve is flagged as failed (treated like a failed Cholesky
 // by the LM loop) and the flag is still published so that no other workgroup is left waiting.
 constexpr unsigned kSpinLimit = 1u << 22;
 
 __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const double* __restrict__ S, int ld,
                                                          int n_pad, int n_blk, double* y,
-                                                         const double* __restrict__ dinv, unsigned* flags,
+                                                         const double* __restrict__ dinv, unsigned long long* gran,
                                                          unsigned* epoch_word, const double* __restrict__ Ld,
                                                          const double* __restrict__ Linv)
 {
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     __shared__ double L[64 * kLd];
     __shared__ double red[4][64];
     __shared__ double ws[64];
+    __shared__ double ys[2][64];
     __shared__ double di[64];
     __shared__ int s_timeout;
     const int m = n_blk - 1 - (int)blockIdx.x;
@@ -690,21 +692,28 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
             for (int r = 0; r < 16; ++r)
                 ln[r] = Lb[(int64_t)r * ld];
         }
-        if (tid == 0) {
-            unsigned n = 0;
-            while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        double* ysj = ys[j & 1];
+        if (part == 0) {   // wave 0 sweeps block j's granules: lane c owns unknown c (two granules)
+            const unsigned long long* g = gran + 2 * (int64_t)(j * kNB + c);
+            unsigned long long x0, x1;
+            for (unsigned n = 0;;) {
+                x0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
+                if (__all(ok))
+                    break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++n > kSpinLimit) {
+                if (++n > kSpinLimit) {   // wave-uniform give-up: flagged as a failed linear solve below
                     s_timeout = 1;
                     break;
                 }
             }
+            ysj[c] = __longlong_as_double((long long)(((x1 & 0xffffffffull) << 32) | (x0 & 0xffffffffull)));
         }
-        __syncthreads();
-        const double* yj = y + j * kNB + part * 16;
+        __syncthreads();   // also orders the reuse of ys[j & 1] two hops later
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            acc += lt[r] * __hip_atomic_load(&yj[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc += lt[r] * ysj[part * 16 + r];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             lt[r] = ln[r];
@@ -751,14 +760,17 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
         }
     }
     if (part == 0) {
-        __hip_atomic_store(&y[K0 + c], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(yv);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        unsigned long long* g = gran + 2 * (int64_t)(K0 + c);
+        __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[K0 + c] = yv;   // for the kernels after this launch
         if (tid == 0) {
             if (s_timeout)
                 ctl->lin_fail = 1;
-            __hip_atomic_store(&flags[m], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (m == 0)
-                *epoch_word = epoch;   // all other workgroups have published, hence read the old value
+                *epoch_word = epoch;   // block 0 is the end of the chain: every other workgroup has read the old value
         }
     }
 }
@@ -871,9 +883,9 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         }
     }
     // one chained launch while every workgroup of the chain can be resident; the per-block kernels otherwise
-    if (n_blk <= 200 && e.flags && !e.no_chain) {
+    if (n_blk <= 200 && e.flags && e.gran && !e.no_chain) {
         hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
-                           e.flags, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
+                           e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
     } else {
         for (int kb = n_blk - 1; kb >= 0; --kb)
             hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y,

@@ -517,6 +517,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Linv, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
     if ((rc = dev_alloc(e, &e.flags, 260))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.gran, (size_t)2 * e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.step_comm, (size_t)6 * e.n_e + 2))) return fail(rc);
     if ((rc = dev_alloc(e, &e.cost_comm, 2))) return fail(rc);
@@ -902,6 +903,7 @@ static int make_scratch(Engine& e, int device, int ld)
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(ld / kNB + 1) * 4096))) return rc;
     if ((rc = dev_alloc(e, &e.Linv, (size_t)(ld / kNB + 1) * 4096))) return rc;
     if ((rc = dev_alloc(e, &e.flags, 260))) return rc;
+    if ((rc = dev_alloc(e, &e.gran, (size_t)2 * ld))) return rc;
     { const char* nc = getenv("VMM_BA_NO_CHAIN"); e.no_chain = nc && nc[0] == '1'; }
     if ((rc = dev_alloc(e, &e.ctl, 1))) return rc;
     return VMM_BA_OK;
