@@ -101,7 +101,7 @@ __device__ __forceinline__ void chol8(const double* __restrict__ D, Piv8& p)
         const double inv = safe_rsqrt(t, okj);
         p.ok = p.ok && okj;
         p.inv[j] = inv;
-        p.l[tri8(j, j)] = (okj ? t : 1.0) * inv;
+        p.l[tri8(j, j)] = t * inv;
 #pragma unroll
         for (int i = j + 1; i < 8; ++i) {
             double v = p.l[tri8(i, j)];
