@@ -251,13 +251,12 @@ __global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, co
 }
 
 // Back-substitution of the eliminated family: y_e = L_e^{-T} (z_e - Z_e y_f), delta_e = -s_e y_e, and
-// the pose's share of the model-cost cross term sum_obs delta_e^T W_ef delta_f.  One wave per
-// eliminated pose (its observations are contiguous in E order).
-template <typename WT>
-__global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose, int f_off_pose,
+// the pose's share of the model-cost cross term sum_obs delta_e^T W_ef delta_f.  With
+// W_ef = s_e^-1 L_e Z_ef s_f^-1 and delta = -s y that share is (L_e^T y_e)^T (Z_e y_f) = (z_e - a)^T a
+// for a = Z_e y_f, which this kernel has anyway: no second pass over the observations and W.
+// One wave per eliminated pose.
+__global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose,
                                                  const int32_t* __restrict__ pose_task,
-                                                 const Task* __restrict__ tasks, const int32_t* __restrict__ other,
-                                                 const WT* __restrict__ W, int64_t n_pad_obs,
                                                  const double* __restrict__ Z, int ldz, int n_red,
                                                  const double* __restrict__ yf, const double* __restrict__ Le,
                                                  const double* __restrict__ ze, const double* __restrict__ scale,
@@ -269,8 +268,7 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
     const int lane = threadIdx.x & 63;
     if (e >= n_e)
         return;
-    const int t0 = pose_task[e], t1 = pose_task[e + 1];
-    const bool owned = t1 > t0;
+    const bool owned = pose_task[e + 1] > pose_task[e];
     if (!owned || ctl->lin_fail) {
         if (lane < 6)
             step_comm[6 * (int64_t)e + lane] = 0.0;
@@ -287,9 +285,13 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
             acc[i] += zr[(int64_t)i * ldz + c] * yv;
     }
     double v[6];
+    double cr = 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-        v[i] = ze[6 * (int64_t)e + i] - wave_sum(acc[i]);
+    for (int i = 0; i < 6; ++i) {
+        const double a = wave_sum(acc[i]);
+        v[i] = ze[6 * (int64_t)e + i] - a;
+        cr += v[i] * a;
+    }
     const double* L = Le + 36 * (int64_t)e;
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
@@ -299,39 +301,13 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
             s -= L[6 * k + i] * v[k];
         v[i] = s / L[6 * i + i];
     }
-    double de[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-        de[i] = -v[i] * scale[6 * (int64_t)(e_off_pose + e) + i];
     if (lane < 6) {
         double out = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-            out = (lane == i) ? de[i] : out;
+            out = (lane == i) ? -v[i] * scale[6 * (int64_t)(e_off_pose + e) + i] : out;
         step_comm[6 * (int64_t)e + lane] = out;
     }
-    // cross term over this pose's observations
-    double cr = 0.0;
-    for (int t = t0; t < t1; ++t) {
-        const Task tk = tasks[t];
-        const int64_t i = (int64_t)tk.begin + lane;
-        if (i < tk.end) {
-            const int f = other[i];
-            double df[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                df[k] = -yf[6 * f + k] * scale[6 * (int64_t)(f_off_pose + f) + k];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double r = 0.0;
-#pragma unroll
-                for (int b = 0; b < 6; ++b)
-                    r += (double)W[(int64_t)(6 * a + b) * n_pad_obs + i] * df[b];
-                cr += de[a] * r;
-            }
-        }
-    }
-    cr = wave_sum(cr);
     if (lane == 0)
         part_cross[e] = cr;
 }
@@ -557,15 +533,8 @@ void launch_iter_begin(Engine& e, const double* src)
 void launch_backsub(Engine& e)
 {
     const int e_off = e.elim_cams ? 0 : e.n_cams;
-    const int f_off = e.elim_cams ? e.n_cams : 0;
-    if (e.f32_accum)
-        hipLaunchKernelGGL((k_backsub<float>), dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, f_off,
-                           e.ordE.pose_task, e.ordE.tasks, e.ordE.other, (const float*)e.Wf, e.ordE.n_pad, e.Z, e.ldz,
-                           e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross);
-    else
-        hipLaunchKernelGGL((k_backsub<double>), dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, f_off,
-                           e.ordE.pose_task, e.ordE.tasks, e.ordE.other, (const double*)e.W, e.ordE.n_pad, e.Z, e.ldz,
-                           e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross);
+    hipLaunchKernelGGL(k_backsub, dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
+                       e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross);
 }
 
 void launch_candidate(Engine& e)
