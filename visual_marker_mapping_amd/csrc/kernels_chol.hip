@@ -6,16 +6,19 @@
 // Matrix layout: row-major, leading dimension ld, only the lower block triangle is used.  Order
 // n_pad = 64 * n_blk; the right-hand side is stored as ROW n_pad of the same array, so the blocked
 // right-looking factorisation also performs the forward substitution (row n_pad ends as (L^-1 b)^T).
-// Per block column k: (1) panel kernel -- every workgroup re-factors the 64x64 diagonal block in LDS
-// (cheaper than a dependent launch), then solves X L_kk^T = A_ik for 256 rows per workgroup with one
-// thread per row, and also stores the panel transposed (P, 64 x ld) so that (2) the trailing update
-// A_ij -= L_ik L_jk^T is the same k-major MFMA f64 rank-k kernel that forms the Schur complement.
-// The back-substitution L^T y = w runs one small kernel per block, last block first.
 //
-// The 64x64 factorisation is latency-bound (64 dependent pivots), so it advances FOUR columns per
-// barrier round: every thread redundantly factors the 4x4 pivot block in registers (no barrier inside
-// the 4 dependent rsqrt chains), then the panel below is solved and the trailing block updated with a
-// rank-4 update.  The diagonal solve of the back-substitution uses the same 4-wide blocking.
+// One launch per block column k (k_chol_step) holds three kinds of workgroups:
+//   * panel: the tall block [A_kk; A_ik] is factored in MFMA accumulators, eight columns per round (the
+//     8x8 pivot block in registers, rows scaled, rank-8 MFMA update); every panel workgroup re-factors the
+//     64x64 diagonal block (cheaper than a dependent launch) and owns 64 rows below it.  It first applies
+//     the rank-64 update of its own block column from panel k-1 (look-ahead), and stores its rows of L to S
+//     and, transposed, to P (64 x ld);
+//   * update: the trailing update A_ij -= L_i,k-1 L_j,k-1^T of panel k-1 for the block columns >= k+1, from
+//     the transposed panel of launch k-1 (k-major operands for v_mfma_f64_16x16x4_f64); the workgroups loop
+//     over the 64x64 tiles with the next tile's operands requested ahead;
+//   * one workgroup inverts the 64x64 diagonal factor of block k-1 for the back-substitution.
+// The back-substitution L^T y = w is ONE launch of n_blk workgroups handing their 64 unknowns on through
+// self-validating granules (k_backsolve_chain); k_backsolve_step is the per-block fallback.
 #include "engine.hpp"
 
 namespace vmm {
