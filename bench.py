@@ -157,7 +157,8 @@ def main():
         n_aug = n_red + 1
         kern = {
             # algorithmic bytes per tag observation: SURVEY.md 8(d) -- 360 B for the fused
-            # residual+Jacobian+accumulate evaluation (72 B in + one f64 6x6 W block out), 72 B cost-only
+            # residual+Jacobian+accumulate evaluation (72 B in + one f64 6x6 W block out), 72 B cost-only.
+            # Timed as the iteration runs it: k_eval_both (both family passes) + k_reduce_pose, two launches.
             "eval_jacobian": {"ms": kt["eval_elim_ms"] + kt["eval_keep_ms"], "bound": "hbm",
                               "alg": (360.0 if precision == "f64" else 216.0) * n_obs, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s"},

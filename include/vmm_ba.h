@@ -152,8 +152,9 @@ typedef int (*vmm_ba_allreduce_fn)(void* user, void* device_buffer, size_t count
 /* Average duration of each device kernel of one LM iteration, measured with HIP events on the
  * engine's own stream (bench.py's roofline leg). */
 typedef struct vmm_ba_kernel_times {
-    double eval_elim_ms;     /* residual+Jacobian+accumulate pass ordered by the eliminated family (writes W) */
-    double eval_keep_ms;     /* the same pass ordered by the kept family */
+    double eval_elim_ms;     /* residual+Jacobian+accumulate as an LM iteration runs it: both family passes in
+                              * one launch (k_eval_both, the eliminated family's pass writes W) + the per-pose sums */
+    double eval_keep_ms;     /* 0 since the two passes share a launch (kept for layout compatibility) */
     double cost_ms;          /* cost-only residual pass */
     double form_z_ms;        /* block factor + Z = L^-1 W */
     double syrk_ms;          /* reduced system: S -= Z^T Z (f64 MFMA) */
