@@ -31,7 +31,7 @@ def traffic(names):
 
 
 groups = {
-    "eval_jacobian": ["k_eval_both<true>"],
+    "eval_jacobian": ["k_eval_both"],
     "eval_cost": ["k_cost<true>"],
     "schur_syrk": ["k_syrk_streamk"],
     "syrk_reduce": ["k_reduce_partials<true>"],
