@@ -185,27 +185,54 @@ def _initial_pose(X, xn):
     return R, t
 
 
+def _rodrigues_batch(r):
+    """(m,3) rotation vectors -> (m,3,3) rotation matrices."""
+    th = np.linalg.norm(r, axis=1)
+    safe = np.where(th > 1e-300, th, 1.0)
+    k = r / safe[:, None]
+    Kx = np.zeros((r.shape[0], 3, 3))
+    Kx[:, 0, 1], Kx[:, 0, 2] = -k[:, 2], k[:, 1]
+    Kx[:, 1, 0], Kx[:, 1, 2] = k[:, 2], -k[:, 0]
+    Kx[:, 2, 0], Kx[:, 2, 1] = -k[:, 1], k[:, 0]
+    s, c = np.sin(th)[:, None, None], np.cos(th)[:, None, None]
+    R = np.eye(3)[None] + s * Kx + (1.0 - c) * (Kx @ Kx)
+    R[th <= 1e-300] = np.eye(3)
+    return R
+
+
+def _residuals_batch(P, X, px, intr, dist):
+    """Residual vectors (m, 2n) of m poses P = (rvec, t) at once -- the arithmetic of project()."""
+    fx, fy, cx, cy = intr
+    k1, k2, p1, p2, k3 = dist
+    R = _rodrigues_batch(P[:, :3])
+    Pc = np.einsum("mij,nj->mni", R, X) + P[:, None, 3:]
+    x = Pc[:, :, 0] / Pc[:, :, 2]
+    y = Pc[:, :, 1] / Pc[:, :, 2]
+    r2 = x * x + y * y
+    rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3))
+    xd = x * rad + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+    yd = y * rad + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+    res = np.stack([fx * xd + cx - px[None, :, 0], fy * yd + cy - px[None, :, 1]], axis=2)
+    return res.reshape(P.shape[0], -1)
+
+
 def refine_pose(R, t, X, px, intr, dist, max_iter=20, eps=1.1920929e-07):
     """Levenberg-Marquardt on the pixel reprojection error over (rvec, t); OpenCV's termination
-    (20 iterations or a relative parameter change below FLT_EPSILON)."""
+    (20 iterations or a relative parameter change below FLT_EPSILON).  Central-difference Jacobian, all
+    twelve perturbed poses evaluated in one vectorised call."""
     p = np.concatenate([rodrigues_inv(R), np.asarray(t, np.float64)])
-
-    def resid(q):
-        return (project(X, rodrigues(q[:3]), q[3:], intr, dist) - px).ravel()
-
-    r = resid(p)
+    r = _residuals_batch(p[None], X, px, intr, dist)[0]
     cost = float(r @ r)
     lam = 1e-3
     for _ in range(max_iter):
-        J = np.empty((r.size, 6))
-        for j in range(6):
-            h = 1e-6 * max(1.0, abs(p[j]))
-            d = np.zeros(6)
-            d[j] = h
-            J[:, j] = (resid(p + d) - resid(p - d)) / (2.0 * h)
+        h = 1e-6 * np.maximum(1.0, np.abs(p))
+        Pp = np.concatenate([p[None] + np.diag(h), p[None] - np.diag(h)])
+        rr = _residuals_batch(Pp, X, px, intr, dist)
+        J = ((rr[:6] - rr[6:]) / (2.0 * h)[:, None]).T
         A = J.T @ J
         g = J.T @ r
         improved = False
+        rel = 0.0
         for _ in range(10):
             try:
                 step = np.linalg.solve(A + lam * np.diag(np.maximum(np.diag(A), 1e-12)), -g)
@@ -213,7 +240,7 @@ def refine_pose(R, t, X, px, intr, dist, max_iter=20, eps=1.1920929e-07):
                 lam *= 10.0
                 continue
             q = p + step
-            rq = resid(q)
+            rq = _residuals_batch(q[None], X, px, intr, dist)[0]
             cq = float(rq @ rq)
             if np.isfinite(cq) and cq < cost:
                 rel = np.linalg.norm(step) / max(np.linalg.norm(p), 1e-300)
@@ -273,6 +300,8 @@ def solvePnPRansac(objectPoints, observations, intr, dist, iterations=100, repro
             best, best_inl = k, inl
             w = k / n
             if w >= 1.0:
+                if len(idx) == n:
+                    return R, t   # the all-points solve itself: nothing to re-fit
                 break
             denom = np.log(max(1.0 - w ** m, 1e-300))
             max_it = min(iterations, int(np.ceil(np.log(1.0 - confidence) / denom))) if denom < 0 else iterations

@@ -152,6 +152,7 @@ class TagReconstructor:
         self.lastSummary = None                                # summary of the last doBundleAdjustment
         self.lastCovariances = None                            # tag id -> 3x3 (last printSummary call)
         self._cached = None                                    # (structure key, BundleAdjuster) of the last call
+        self._obs_cache = None                                 # observation list as arrays (see _obs_arrays)
 
     # -- trivial accessors (src/TagReconstructor.cpp:75-84, 818-842) --
     def getLowestTag(self):
@@ -305,27 +306,37 @@ class TagReconstructor:
         print("Finished transforming Tags")
 
     # -- packing of the map state into the flat arrays of the C-ABI --
+    def _obs_arrays(self):
+        """The observation list as arrays (image id, tag id, 8 pixel coordinates), rebuilt only when the list object
+        or its length changes: the incremental driver packs the problem three times per image."""
+        obs = self.detectionResults_.tagObservations
+        key = (id(obs), len(obs))
+        if self._obs_cache is None or self._obs_cache[0] != key:
+            img = np.fromiter((ob.imageId for ob in obs), np.int64, len(obs))
+            tag = np.fromiter((ob.tagId for ob in obs), np.int64, len(obs))
+            px = (np.stack([np.asarray(ob.corners, np.float64).reshape(8) for ob in obs]) if len(obs)
+                  else np.zeros((0, 8)))
+            self._obs_cache = (key, img, tag, px)
+        return self._obs_cache[1:]
+
     def _pack(self, for_ba):
         """Dense problem arrays exactly as doBundleAdjustment assembles the ceres::Problem
         (src/TagReconstructor.cpp:663-724): tags in map (id) order; cameras with >= 1 reconstructed tag
         in map order (for_ba) or all cameras (statistics); observations whose camera and tag are both
         reconstructed, in file order."""
         tag_ids = sorted(self.reconstructedTags)
-        tag_index = {tid: k for k, tid in enumerate(tag_ids)}
-        tag_by_id = {t.tagId: t for t in self.detectionResults_.tags}
-        num_tags_in_image = {}
-        for ob in self.detectionResults_.tagObservations:
-            if ob.tagId in tag_index:
-                num_tags_in_image[ob.imageId] = num_tags_in_image.get(ob.imageId, 0) + 1   # :679-684
+        ob_img, ob_tag, ob_px = self._obs_arrays()
+        tag_arr = np.asarray(tag_ids, np.int64)
+        tag_ok = np.isin(ob_tag, tag_arr)
+        images_with_tags = set(np.unique(ob_img[tag_ok]).tolist())                            # :679-684
         cam_ids = [cid for cid in sorted(self.reconstructedCameras)
-                   if (num_tags_in_image.get(cid, 0) > 0 or not for_ba)]                    # :689-690
-        cam_index = {cid: k for k, cid in enumerate(cam_ids)}
-        obs_cam, obs_tag, obs_px = [], [], []
-        for ob in self.detectionResults_.tagObservations:                                    # :699-708
-            if ob.imageId in cam_index and ob.tagId in tag_index:
-                obs_cam.append(cam_index[ob.imageId])
-                obs_tag.append(tag_index[ob.tagId])
-                obs_px.append(np.asarray(ob.corners, np.float64).reshape(8))
+                   if (cid in images_with_tags or not for_ba)]                               # :689-690
+        cam_arr = np.asarray(cam_ids, np.int64)
+        keep = tag_ok & np.isin(ob_img, cam_arr)                                              # :699-708
+        # ids -> dense indices (both id lists are sorted)
+        obs_cam = np.searchsorted(cam_arr, ob_img[keep]).astype(np.int32)
+        obs_tag = np.searchsorted(tag_arr, ob_tag[keep]).astype(np.int32)
+        obs_px = ob_px[keep]
         cam_qt = np.array([np.r_[self.reconstructedCameras[c].q, self.reconstructedCameras[c].t] for c in cam_ids],
                           np.float64).reshape(-1, 7)
         tag_qt = np.array([np.r_[self.reconstructedTags[t].q, self.reconstructedTags[t].t] for t in tag_ids],
@@ -334,13 +345,11 @@ class TagReconstructor:
         # reconstructed tag's (:713 vs :718); only the quad enters the arithmetic
         tag_wh = np.array([[self.reconstructedTags[t].tagWidth, self.reconstructedTags[t].tagHeight] for t in tag_ids],
                           np.float64).reshape(-1, 2)
-        _ = tag_by_id
-        fixed = tag_index.get(self.originTagId, -1)                                          # :669-673
+        fixed = tag_ids.index(self.originTagId) if self.originTagId in self.reconstructedTags else -1   # :669-673
         intr = [self.camModel.fx, self.camModel.fy, self.camModel.cx, self.camModel.cy]
         return dict(tag_ids=tag_ids, cam_ids=cam_ids, intr=intr, dist=self.camModel.distortionCoefficients,
                     cam_qt=cam_qt, tag_qt=tag_qt, tag_wh=tag_wh, fixed=fixed,
-                    obs_cam=np.asarray(obs_cam, np.int32), obs_tag=np.asarray(obs_tag, np.int32),
-                    obs_px=np.asarray(obs_px, np.float64).reshape(-1, 8))
+                    obs_cam=obs_cam, obs_tag=obs_tag, obs_px=np.ascontiguousarray(obs_px, np.float64).reshape(-1, 8))
 
     def _engine_for(self, p, **kw):
         """A device handle for the packed problem.  The handle of the previous call is kept and reused when the
