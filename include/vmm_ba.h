@@ -184,6 +184,14 @@ int vmm_ba_get_state(vmm_ba_handle h, double* cam_qt, double* tag_qt);
 
 int vmm_ba_set_allreduce(vmm_ba_handle h, vmm_ba_allreduce_fn fn, void* user);
 
+/* Switches observations off and on without rebuilding the handle: mask[i] != 0 keeps observation i (the
+ * caller's order), NULL keeps all.  This is how the incremental driver (src/TagReconstructor.cpp:86-278: one
+ * more image per bundle adjustment, observations of unreconstructed tags skipped at :699-708) grows its problem
+ * on the device: one handle for the whole detection set, a mask per step.  A pose left without an active
+ * observation drops out of the reduced program exactly like a pose without observations.  The poses of
+ * switched-off observations must still be finite numbers (they are evaluated and weighted 0). */
+int vmm_ba_set_observation_mask(vmm_ba_handle h, const uint8_t* mask);
+
 /* Replaces ceres::Solve at src/TagReconstructor.cpp:737-738. */
 int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* summary);
 

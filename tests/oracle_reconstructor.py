@@ -11,6 +11,10 @@ class OracleReconstructor(TagReconstructor):
         super().__init__(detection_result, device)
         self.ba_calls = []
 
+    def startReconstruction(self, numThreads=1, deviceResident=False):
+        # the oracle solves the problem of each step as packed from scratch (no device handle, no mask)
+        return super().startReconstruction(numThreads, deviceResident=False)
+
     def doBundleAdjustment(self, maxNumIterations, ceresThreads=1, robustify=True, printSummary=False, **kw):
         from oracle import oracle as O
         p = self._pack(for_ba=True)

@@ -39,7 +39,16 @@ def test_start_reconstruction_matches_oracle_driven_run(tmp_path, capsys):
     cpu.startReconstruction(4)
     assert sorted(gpu.reconstructedTags) == sorted(cpu.reconstructedTags)
     assert sorted(gpu.reconstructedCameras) == sorted(cpu.reconstructedCameras)
+    # the rebuilt-handle variant of the driver gives the same reconstruction as the device-resident one
+    cold = TagReconstructor(vio.readDetectionResult(str(tmp_path / "marker_detections.json")))
+    cold.setCameraModel(model)
+    cold.startReconstruction(4, deviceResident=False)
+    capsys.readouterr()
+    assert sorted(cold.reconstructedTags) == sorted(gpu.reconstructedTags)
+    tcold, ccold = _flat(cold)
     tg, cg = _flat(gpu)
+    np.testing.assert_allclose(tg, tcold, rtol=0, atol=1e-7 * max(1.0, np.abs(tcold).max()))
+    np.testing.assert_allclose(cg, ccold, rtol=0, atol=1e-7 * max(1.0, np.abs(ccold).max()))
     tc, cc = _flat(cpu)
     np.testing.assert_allclose(tg, tc, rtol=0, atol=1e-5 * max(1.0, np.abs(tc).max()))
     np.testing.assert_allclose(cg, cc, rtol=0, atol=1e-5 * max(1.0, np.abs(cc).max()))

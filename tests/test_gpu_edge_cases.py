@@ -85,3 +85,53 @@ def test_zero_iterations_and_empty_problem(oracle):
         ba.close()
     assert out["termination_type"] == eng.CONVERGENCE and np.array_equal(cam, s.cam_init) and np.array_equal(tag, s.tag_init)
     assert np.all(pc == -1.0) and np.all(np.isnan(pt)) and corner.shape == (0, 8)
+
+
+def test_observation_mask_equals_a_rebuilt_subproblem(oracle):
+    """vmm_ba_set_observation_mask: one handle for the whole detection set, a mask per step of the incremental
+    driver.  Switching off every observation of cameras 5.. and of tag 3 must give the solve, the statistics and
+    the covariance of the handle built from the remaining observations only (poses that lose all observations
+    drop out like poses without observations)."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(5, n_cams=9, n_tags=7, visibility=0.8)
+    keep = (s.obs_cam < 5) & (s.obs_tag != 3)
+    full = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px)
+    sub = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam[keep], s.obs_tag[keep],
+                             s.obs_px[keep])
+    try:
+        full.set_observation_mask(keep)
+        assert full.cost(robustify=True) == pytest.approx(sub.cost(robustify=True), rel=1e-12)
+        o = eng.default_options(robustify=1)
+        a, b = full.solve(o, trace_capacity=64), sub.solve(o, trace_capacity=64)
+        assert a["iterations"] == b["iterations"] and a["termination_type"] == b["termination_type"]
+        for x, y in zip(a["trace"], b["trace"]):
+            assert x["step_is_successful"] == y["step_is_successful"]
+            np.testing.assert_allclose(x["cost"], y["cost"], rtol=1e-9)
+        (ca, ta), (cb, tb) = full.get_state(), sub.get_state()
+        np.testing.assert_allclose(ca, cb, rtol=0, atol=1e-9 * np.abs(cb).max())
+        np.testing.assert_allclose(ta, tb, rtol=0, atol=1e-9 * np.abs(tb).max())
+        assert np.array_equal(ca[5:], s.cam_init[5:]) and np.array_equal(ta[3], s.tag_init[3])   # switched off: untouched
+        pa, pb = full.reprojection_stats(), sub.reprojection_stats()
+        np.testing.assert_allclose(pa[0], pb[0], rtol=1e-9)
+        np.testing.assert_allclose(pa[1], pb[1], rtol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(pa[2], pb[2], rtol=1e-9)
+        assert np.all(pa[0][5:] == -1.0) and np.isnan(pa[1][3])
+        np.testing.assert_allclose(pa[3][keep], pb[3], rtol=1e-9, atol=1e-12)
+        assert np.all(pa[3][~keep] == 0.0)
+        np.testing.assert_allclose(full.tag_translation_covariance(True), sub.tag_translation_covariance(True),
+                                   rtol=1e-6, atol=1e-18)
+        # back to all observations: the same as a handle that never had a mask
+        full.set_observation_mask(None)
+        full.set_state(s.cam_init, s.tag_init)
+        ref = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px)
+        try:
+            a, b = full.solve(o), ref.solve(o)
+            assert a["iterations"] == b["iterations"] and a["final_cost"] == b["final_cost"]
+        finally:
+            ref.close()
+        with pytest.raises(ValueError):
+            full.set_observation_mask(keep[:-1])
+    finally:
+        full.close()
+        sub.close()

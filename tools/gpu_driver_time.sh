@@ -1,7 +1,8 @@
-# wall time of the incremental driver (startReconstruction) on a 60 x 40 scene, with and without handle reuse
+# wall time of the incremental driver (startReconstruction) on a 60 x 40 scene: device-resident handle + masks,
+# rebuilt handles (with reuse between a solve and its statistics), rebuilt handles without reuse
 cd $GRAFT_REPO_ROOT
-for nc in 0 1; do
-VMM_BA_NO_HANDLE_CACHE=$( [ $nc = 1 ] && echo 1 ) timeout -k 10 500 python - <<'PY'
+for mode in resident cold cold_nocache; do
+VMM_DRIVER_MODE=$mode VMM_BA_NO_HANDLE_CACHE=$( [ $mode = cold_nocache ] && echo 1 ) timeout -k 10 500 python - <<'PY'
 import os, sys, time, io, contextlib
 sys.path.insert(0, '.')
 from visual_marker_mapping_amd import synthetic
@@ -11,12 +12,12 @@ det = detection_result_from_arrays(s.obs_cam, s.obs_tag, s.obs_px, s.tag_wh, 60)
 rec = TagReconstructor(det)
 rec.setCameraModel(CameraModel(*s.intr, s.dist, 4000, 6000))
 buf = io.StringIO()
+mode = os.environ["VMM_DRIVER_MODE"]
 t0 = time.time()
 with contextlib.redirect_stdout(buf):
-    rec.startReconstruction(1)
+    rec.startReconstruction(1, deviceResident=(mode == "resident"))
 dt = time.time() - t0
-print("handle cache %s: startReconstruction 60 x 40: %.2f s, %d cameras, %d tags, %d BA solves" % (
-    "off" if os.environ.get("VMM_BA_NO_HANDLE_CACHE") else "on", dt, len(rec.reconstructedCameras),
-    len(rec.reconstructedTags), buf.getvalue().count("Solution ")))
+print("%-13s startReconstruction 60 x 40: %.2f s, %d cameras, %d tags, %d BA solves" % (
+    mode, dt, len(rec.reconstructedCameras), len(rec.reconstructedTags), buf.getvalue().count("Solution ")))
 PY
 done

@@ -17,7 +17,7 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 # every symbol include/vmm_ba.h declares
 EXPORTS = ["vmm_ba_last_error", "vmm_ba_abi_version", "vmm_ba_default_options",
            "vmm_ba_default_create_options", "vmm_ba_create", "vmm_ba_destroy", "vmm_ba_set_state",
-           "vmm_ba_get_state", "vmm_ba_set_allreduce", "vmm_ba_solve", "vmm_ba_cost",
+           "vmm_ba_get_state", "vmm_ba_set_allreduce", "vmm_ba_set_observation_mask", "vmm_ba_solve", "vmm_ba_cost",
            "vmm_ba_reprojection_stats", "vmm_ba_tag_translation_covariance", "vmm_ba_project_points", "vmm_ba_eval_blocks",
            "vmm_ba_dense_spd_solve", "vmm_ba_dense_syrk", "vmm_ba_time_kernels"]
 
@@ -96,6 +96,7 @@ def lib():
         L.vmm_ba_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.vmm_ba_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.vmm_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.vmm_ba_set_observation_mask.argtypes = [C.c_void_p, C.c_void_p]
         L.vmm_ba_solve.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Summary)]
         L.vmm_ba_cost.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]
         L.vmm_ba_reprojection_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,

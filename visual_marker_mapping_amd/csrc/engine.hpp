@@ -104,6 +104,7 @@ struct Engine {
     double* small_stage = nullptr;
     double *ev_H_cam = nullptr, *ev_H_tag = nullptr, *ev_g_cam = nullptr, *ev_g_tag = nullptr, *ev_cost = nullptr;
     double* W = nullptr;            // [36][ordE.n_pad]: J_e^T J_f per observation, E order (f64 precision)
+    uint8_t* obs_mask = nullptr;    // [n_obs] caller order, 1 = observation active (vmm_ba_set_observation_mask)
     float* Wf = nullptr;            // the same in f32 (VMM_BA_PRECISION_F32_ACCUM); exactly one of the two exists
     bool f32_accum = false;
 
@@ -159,7 +160,7 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
 void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a);
 void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a,
                  double* out_scalar);
-void launch_stats(Engine& e, double* part_cam, double* part_tag, double* per_corner_dev);
+void launch_stats(Engine& e, double* part_cam, double* part_tag, int32_t* n_cam, int32_t* n_tag, double* per_corner_dev);
 void launch_project(hipStream_t st, const Intrinsics& K, int64_t n, const double* pc, double* uv);
 void launch_sum(Engine& e, bool guard, const double* in, int n, double* out);
 // kernels_schur.hip

@@ -31,6 +31,8 @@ struct EvalArgs {
     double huber_a;
     double* part;              // [n_tasks][kPart]
     void* W;                   // [36][n_pad] of AT (double or float) or null
+    const int32_t* caller;     // position of each sorted observation in the caller's order
+    const uint8_t* mask;       // [n_obs] caller order: 0 = observation switched off (vmm_ba_set_observation_mask)
     const LmCtl* ctl;          // null: always run
     int guard_need_jacobian;
 };
@@ -60,7 +62,8 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
     const double hw = 0.5 * a.tag_wh[2 * tag_idx], hh = 0.5 * a.tag_wh[2 * tag_idx + 1];
     // a constant (origin) tag contributes no Jacobian columns (src/TagReconstructor.cpp:669-673)
     const double tag_on = (tag_idx == a.fixed_tag) ? 0.0 : 1.0;
-    const double mask = valid ? 1.0 : 0.0;
+    // switched-off observations are evaluated like the others (their poses must be finite) and weighted 0
+    const double mask = (valid && a.mask[a.caller[is]]) ? 1.0 : 0.0;
 
     AT H[21];
     double g[6], cost = 0.0;
@@ -267,6 +270,8 @@ struct CostArgs {
     int robustify;
     double huber_a;
     double* part;  // [n_tasks]
+    const int32_t* caller;
+    const uint8_t* mask;
     const LmCtl* ctl;
 };
 
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void k_cost(const CostArgs a)
         huber(a.robustify != 0, a.huber_a, e.ru * e.ru + e.rv * e.rv, rho0, wgt);
         cost += 0.5 * rho0;
     }
-    cost = wave_sum(valid ? cost : 0.0);
+    cost = wave_sum((valid && a.mask[a.caller[is]]) ? cost : 0.0);
     if (lane == 0)
         a.part[wave] = cost;
 }
@@ -323,7 +328,9 @@ struct StatsArgs {
     const double* other_pose;
     const double* tag_wh;
     double* part;        // [n_tasks]
-    double* per_corner;  // [8*n_obs] caller order, or null
+    int32_t* part_n;     // [n_tasks] active observations of the task
+    double* per_corner;  // [8*n_obs] caller order, or null (zeros for switched-off observations)
+    const uint8_t* mask; // [n_obs] caller order
 };
 
 template <bool OWN_IS_CAM>
@@ -345,6 +352,8 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a)
     const Rigid& tag = OWN_IS_CAM ? oth : own;
     const int tag_idx = OWN_IS_CAM ? o : t.pose;
     const double hw = 0.5 * a.tag_wh[2 * tag_idx], hh = 0.5 * a.tag_wh[2 * tag_idx + 1];
+    const int64_t ci = a.caller[is];
+    const bool on = valid && a.mask[ci];
     double sum = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -355,14 +364,16 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a)
                                   a.px[(2 * c + 1) * a.n_pad + is], e);
         sum += sqrt(e.ru * e.ru + e.rv * e.rv);
         if (a.per_corner && valid) {
-            const int64_t ci = a.caller[i];
-            a.per_corner[8 * ci + 2 * c] = e.ru;
-            a.per_corner[8 * ci + 2 * c + 1] = e.rv;
+            a.per_corner[8 * ci + 2 * c] = on ? e.ru : 0.0;
+            a.per_corner[8 * ci + 2 * c + 1] = on ? e.rv : 0.0;
         }
     }
-    sum = wave_sum(valid ? sum : 0.0);
-    if (lane == 0)
+    sum = wave_sum(on ? sum : 0.0);
+    const int n_on = __popcll(__ballot(on));
+    if (lane == 0) {
         a.part[wave] = sum;
+        a.part_n[wave] = n_on;
+    }
 }
 
 // CameraModel::projectPoint (src/CameraModel.cpp:6-26) for a batch of camera-frame points.
@@ -404,6 +415,8 @@ static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, 
     a.huber_a = 1.0;
     a.part = ord.part;
     a.W = W;
+    a.caller = ord.caller;
+    a.mask = e.obs_mask;
     a.ctl = e.ctl;
     a.guard_need_jacobian = guard ? 1 : 0;
     return a;
@@ -509,6 +522,8 @@ void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool gu
     a.robustify = robustify;
     a.huber_a = huber_a;
     a.part = e.part_k1;
+    a.caller = e.ordE.caller;
+    a.mask = e.obs_mask;
     a.ctl = guard ? e.ctl : nullptr;
     if (a.n_tasks <= 0)
         return;
@@ -525,20 +540,21 @@ void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, in
     launch_sum(e, guard, e.part_k1, e.ordE.n_tasks, out_scalar);
 }
 
-void launch_stats(Engine& e, double* part_cam, double* part_tag, double* per_corner_dev)
+void launch_stats(Engine& e, double* part_cam, double* part_tag, int32_t* n_cam, int32_t* n_tag, double* per_corner_dev)
 {
     const ObsOrder& oc = e.elim_cams ? e.ordE : e.ordF;  // sorted by camera
     const ObsOrder& ot = e.elim_cams ? e.ordF : e.ordE;  // sorted by tag
     StatsArgs a;
     a.K = e.K;
     a.tag_wh = e.tag_wh;
+    a.mask = e.obs_mask;
     a.tasks = oc.tasks; a.n_tasks = oc.n_tasks; a.other = oc.other; a.caller = oc.caller; a.px = oc.px;
-    a.n_pad = oc.n_pad; a.own_pose = e.cam_qt; a.other_pose = e.tag_qt; a.part = part_cam;
+    a.n_pad = oc.n_pad; a.own_pose = e.cam_qt; a.other_pose = e.tag_qt; a.part = part_cam; a.part_n = n_cam;
     a.per_corner = per_corner_dev;
     if (a.n_tasks > 0)
         hipLaunchKernelGGL((k_stats<true>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);
     a.tasks = ot.tasks; a.n_tasks = ot.n_tasks; a.other = ot.other; a.caller = ot.caller; a.px = ot.px;
-    a.n_pad = ot.n_pad; a.own_pose = e.tag_qt; a.other_pose = e.cam_qt; a.part = part_tag;
+    a.n_pad = ot.n_pad; a.own_pose = e.tag_qt; a.other_pose = e.cam_qt; a.part = part_tag; a.part_n = n_tag;
     a.per_corner = nullptr;
     if (a.n_tasks > 0)
         hipLaunchKernelGGL((k_stats<false>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);

@@ -486,6 +486,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.ev_g_cam = e.ev_H_tag + (size_t)36 * e.n_tags;
     e.ev_g_tag = e.ev_g_cam + (size_t)6 * e.n_cams;
     e.ev_cost = e.ev_g_tag + (size_t)6 * e.n_tags;
+    if ((rc = dev_alloc(e, &e.obs_mask, (size_t)std::max<int64_t>(e.n_obs, 1), false))) return fail(rc);
+    HIP_TRY(hipMemsetAsync(e.obs_mask, 1, (size_t)std::max<int64_t>(e.n_obs, 1), e.stream));
     if (e.f32_accum) {
         if ((rc = dev_alloc(e, &e.Wf, (size_t)36 * e.ordE.n_pad))) return fail(rc);
     } else if ((rc = dev_alloc(e, &e.W, (size_t)36 * e.ordE.n_pad))) return fail(rc);
@@ -680,6 +682,28 @@ int vmm_ba_cost(vmm_ba_handle h, int robustify, double huber_a, double* cost)
     return VMM_BA_OK;
 }
 
+int vmm_ba_set_observation_mask(vmm_ba_handle h, const uint8_t* mask)
+{
+    if (!h) {
+        set_error("null handle");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    HIP_TRY(hipSetDevice(e.device));
+    if (e.n_obs == 0)
+        return VMM_BA_OK;
+    if (mask) {
+        std::vector<uint8_t> m((size_t)e.n_obs);
+        for (int64_t i = 0; i < e.n_obs; ++i)
+            m[(size_t)i] = mask[i] ? 1 : 0;
+        HIP_TRY(hipMemcpyAsync(e.obs_mask, m.data(), m.size(), hipMemcpyHostToDevice, e.stream));
+        HIP_TRY(hipStreamSynchronize(e.stream));   // the staging vector goes out of scope
+    } else {
+        HIP_TRY(hipMemsetAsync(e.obs_mask, 1, (size_t)e.n_obs, e.stream));
+    }
+    return VMM_BA_OK;
+}
+
 int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per_tag_mean, double* avg,
                               double* per_corner)
 {
@@ -692,17 +716,23 @@ int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per
     const ObsOrder& oc = e.elim_cams ? e.ordE : e.ordF;
     const ObsOrder& ot = e.elim_cams ? e.ordF : e.ordE;
     double *d_pc = nullptr, *d_pt = nullptr, *d_corner = nullptr;
+    int32_t *d_nc = nullptr, *d_nt = nullptr;
     HIP_TRY(hipMalloc((void**)&d_pc, sizeof(double) * std::max(1, oc.n_tasks)));
     HIP_TRY(hipMalloc((void**)&d_pt, sizeof(double) * std::max(1, ot.n_tasks)));
+    HIP_TRY(hipMalloc((void**)&d_nc, sizeof(int32_t) * std::max(1, oc.n_tasks)));
+    HIP_TRY(hipMalloc((void**)&d_nt, sizeof(int32_t) * std::max(1, ot.n_tasks)));
     if (per_corner && e.n_obs > 0)
         HIP_TRY(hipMalloc((void**)&d_corner, sizeof(double) * 8 * e.n_obs));
-    launch_stats(e, d_pc, d_pt, d_corner);
+    launch_stats(e, d_pc, d_pt, d_nc, d_nt, d_corner);
     std::vector<double> pc((size_t)oc.n_tasks), pt((size_t)ot.n_tasks);
+    std::vector<int32_t> cnc((size_t)oc.n_tasks), cnt((size_t)ot.n_tasks);
     std::vector<Task> tc((size_t)oc.n_tasks), tt((size_t)ot.n_tasks);
     hipError_t err = hipSuccess;
     if (oc.n_tasks > 0) {
         err = hipMemcpyAsync(pc.data(), d_pc, sizeof(double) * pc.size(), hipMemcpyDeviceToHost, e.stream);
         if (err == hipSuccess) err = hipMemcpyAsync(pt.data(), d_pt, sizeof(double) * pt.size(), hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess) err = hipMemcpyAsync(cnc.data(), d_nc, sizeof(int32_t) * cnc.size(), hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess) err = hipMemcpyAsync(cnt.data(), d_nt, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost, e.stream);
         if (err == hipSuccess) err = hipMemcpyAsync(tc.data(), oc.tasks, sizeof(Task) * tc.size(), hipMemcpyDeviceToHost, e.stream);
         if (err == hipSuccess) err = hipMemcpyAsync(tt.data(), ot.tasks, sizeof(Task) * tt.size(), hipMemcpyDeviceToHost, e.stream);
     }
@@ -712,6 +742,8 @@ int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per
         err = hipStreamSynchronize(e.stream);
     (void)hipFree(d_pc);
     (void)hipFree(d_pt);
+    (void)hipFree(d_nc);
+    (void)hipFree(d_nt);
     if (d_corner)
         (void)hipFree(d_corner);
     if (err != hipSuccess) {
@@ -724,11 +756,11 @@ int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per
     std::vector<int64_t> nc((size_t)e.n_cams, 0), nt((size_t)e.n_tags, 0);
     for (size_t k = 0; k < tc.size(); ++k) {
         sc[tc[k].pose] += pc[k];
-        nc[tc[k].pose] += 4 * (int64_t)(tc[k].end - tc[k].begin);
+        nc[tc[k].pose] += 4 * (int64_t)cnc[k];   // active observations only
     }
     for (size_t k = 0; k < tt.size(); ++k) {
         st[tt[k].pose] += pt[k];
-        nt[tt[k].pose] += 4 * (int64_t)(tt[k].end - tt[k].begin);
+        nt[tt[k].pose] += 4 * (int64_t)cnt[k];
     }
     if (per_cam_mean)
         for (int c = 0; c < e.n_cams; ++c)

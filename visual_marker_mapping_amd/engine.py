@@ -79,6 +79,16 @@ class BundleAdjuster:
         tag = None if tag_qt is None else np.ascontiguousarray(tag_qt, np.float64).reshape(self.n_tags, 7)
         _lib.check(_lib.lib().vmm_ba_set_state(self._h, _ptr(cam), _ptr(tag)))
 
+    def set_observation_mask(self, mask=None):
+        """Switches observations off/on (caller's order; None = all on) without rebuilding the handle."""
+        if mask is None:
+            _lib.check(_lib.lib().vmm_ba_set_observation_mask(self._h, None))
+            return
+        m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8).reshape(-1)
+        if len(m) != self.n_obs:
+            raise ValueError("mask length differs from the number of observations")
+        _lib.check(_lib.lib().vmm_ba_set_observation_mask(self._h, m.ctypes.data_as(C.c_void_p)))
+
     def get_state(self):
         cam, tag = np.zeros((self.n_cams, 7)), np.zeros((self.n_tags, 7))
         _lib.check(_lib.lib().vmm_ba_get_state(self._h, _ptr(cam), _ptr(tag)))

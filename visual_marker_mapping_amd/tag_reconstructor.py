@@ -153,6 +153,8 @@ class TagReconstructor:
         self.lastCovariances = None                            # tag id -> 3x3 (last printSummary call)
         self._cached = None                                    # (structure key, BundleAdjuster) of the last call
         self._obs_cache = None                                 # observation list as arrays (see _obs_arrays)
+        self._resident = False                                 # device-resident packing (startReconstruction)
+        self._full = None                                      # the whole detection set as problem arrays
 
     # -- trivial accessors (src/TagReconstructor.cpp:75-84, 818-842) --
     def getLowestTag(self):
@@ -186,8 +188,13 @@ class TagReconstructor:
     def setOriginTagId(self, originTagId):
         self.originTagId = int(originTagId)
 
-    def startReconstruction(self, numThreads=1):
-        """The incremental driver, src/TagReconstructor.cpp:86-278: origin tag at identity; the image that
+    def startReconstruction(self, numThreads=1, deviceResident=True):
+        """deviceResident: ONE device handle holds every image, tag and observation of the detection result for
+        the whole run and each of the N+2 bundle adjustments / prunings only sends an observation mask and the
+        poses (vmm_ba_set_observation_mask); False rebuilds a handle whenever the problem structure changes.
+        Same results either way (tests/test_gpu_driver.py).
+
+        The incremental driver, src/TagReconstructor.cpp:86-278: origin tag at identity; the image that
         sees the origin tag and the most tags first; then per image: camera pose from the already
         reconstructed tags (PnP+RANSAC), every new tag seen in >= 2 images from its own four corners (PnP),
         robust bundle adjustment (400 iterations), pruning of tags above 2 px; next = the image with the most
@@ -196,6 +203,15 @@ class TagReconstructor:
         The bundle adjustments and the reprojection statistics run on the MI355X through libvmm_ba; the two
         PnP initialisations are host code in pnp.py (OpenCV's role in the reference)."""
         from . import pnp as _pnp
+        self._resident = bool(deviceResident)
+        try:
+            self._start_reconstruction(numThreads, _pnp)
+        finally:
+            self._resident = False
+            self._drop_cached()
+            self._full = None
+
+    def _start_reconstruction(self, numThreads, _pnp):
         if self.originTagId == -1:
             self.originTagId = self.getLowestTag()
         intr = (self.camModel.fx, self.camModel.fy, self.camModel.cx, self.camModel.cy)
@@ -324,6 +340,8 @@ class TagReconstructor:
         (src/TagReconstructor.cpp:663-724): tags in map (id) order; cameras with >= 1 reconstructed tag
         in map order (for_ba) or all cameras (statistics); observations whose camera and tag are both
         reconstructed, in file order."""
+        if self._resident:
+            return self._pack_resident(for_ba)
         tag_ids = sorted(self.reconstructedTags)
         ob_img, ob_tag, ob_px = self._obs_arrays()
         tag_arr = np.asarray(tag_ids, np.int64)
@@ -349,26 +367,82 @@ class TagReconstructor:
         intr = [self.camModel.fx, self.camModel.fy, self.camModel.cx, self.camModel.cy]
         return dict(tag_ids=tag_ids, cam_ids=cam_ids, intr=intr, dist=self.camModel.distortionCoefficients,
                     cam_qt=cam_qt, tag_qt=tag_qt, tag_wh=tag_wh, fixed=fixed,
-                    obs_cam=obs_cam, obs_tag=obs_tag, obs_px=np.ascontiguousarray(obs_px, np.float64).reshape(-1, 8))
+                    obs_cam=obs_cam, obs_tag=obs_tag, obs_px=np.ascontiguousarray(obs_px, np.float64).reshape(-1, 8),
+                    cam_rows=list(range(len(cam_ids))), tag_rows=list(range(len(tag_ids))), mask=None, key=None,
+                    n_active=int(len(obs_cam)))
+
+    def _pack_resident(self, for_ba):
+        """Device-resident variant used by startReconstruction: the arrays describe EVERY image, tag and
+        observation of the detection result (built once), and the step's problem is a mask over the observations
+        (camera and tag both reconstructed, :699-708) -- vmm_ba_set_observation_mask.  cam_ids / tag_ids list the
+        poses of this step like the cold packing does; cam_rows / tag_rows are their rows in the full arrays.
+        Poses that are not reconstructed yet sit at harmless finite defaults; they have no active observation."""
+        ob_img, ob_tag, ob_px = self._obs_arrays()
+        full = self._full
+        if full is None or full["src"] is not self._obs_cache:
+            all_cams = np.unique(np.concatenate([ob_img, np.asarray([i.imageId for i in self.detectionResults_.images],
+                                                                    np.int64)]))
+            det_tags = {t.tagId: t for t in self.detectionResults_.tags}
+            all_tags = np.unique(np.concatenate([ob_tag, np.asarray(sorted(det_tags), np.int64)]))
+            wh = np.array([[det_tags[t].width, det_tags[t].height] if t in det_tags else [1.0, 1.0]
+                           for t in all_tags.tolist()], np.float64).reshape(-1, 2)
+            full = dict(src=self._obs_cache, cams=all_cams, tags=all_tags, tag_wh=wh,
+                        obs_cam=np.searchsorted(all_cams, ob_img).astype(np.int32),
+                        obs_tag=np.searchsorted(all_tags, ob_tag).astype(np.int32),
+                        obs_px=np.ascontiguousarray(ob_px, np.float64).reshape(-1, 8))
+            self._full = full
+        tag_ids = sorted(self.reconstructedTags)
+        tag_arr = np.asarray(tag_ids, np.int64)
+        rec_cams = np.asarray(sorted(self.reconstructedCameras), np.int64)
+        tag_ok = np.isin(ob_tag, tag_arr)
+        mask = tag_ok & np.isin(ob_img, rec_cams)
+        images_with_tags = set(np.unique(ob_img[mask]).tolist())
+        cam_ids = [c for c in rec_cams.tolist() if (c in images_with_tags or not for_ba)]
+        cam_rows = np.searchsorted(full["cams"], np.asarray(cam_ids, np.int64)).tolist()
+        tag_rows = np.searchsorted(full["tags"], tag_arr).tolist()
+        cam_qt = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 1.0]), (len(full["cams"]), 1))   # identity, 1 m in front
+        tag_qt = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0.0]), (len(full["tags"]), 1))
+        for c, r in zip(cam_ids, cam_rows):
+            cam_qt[r] = np.r_[self.reconstructedCameras[c].q, self.reconstructedCameras[c].t]
+        tag_wh = full["tag_wh"].copy()
+        for t, r in zip(tag_ids, tag_rows):
+            tag_qt[r] = np.r_[self.reconstructedTags[t].q, self.reconstructedTags[t].t]
+            tag_wh[r] = (self.reconstructedTags[t].tagWidth, self.reconstructedTags[t].tagHeight)
+        fixed = (int(np.searchsorted(full["tags"], self.originTagId))
+                 if self.originTagId in self.reconstructedTags else -1)
+        intr = [self.camModel.fx, self.camModel.fy, self.camModel.cx, self.camModel.cy]
+        key = ("resident", id(full), fixed, tuple(float(v) for v in intr),
+               tuple(float(v) for v in self.camModel.distortionCoefficients), tag_wh.tobytes())
+        return dict(tag_ids=tag_ids, cam_ids=cam_ids, cam_rows=cam_rows, tag_rows=tag_rows, intr=intr,
+                    dist=self.camModel.distortionCoefficients, cam_qt=cam_qt, tag_qt=tag_qt, tag_wh=tag_wh,
+                    fixed=fixed, obs_cam=full["obs_cam"], obs_tag=full["obs_tag"], obs_px=full["obs_px"],
+                    mask=mask, key=key, n_active=int(mask.sum()))
 
     def _engine_for(self, p, **kw):
         """A device handle for the packed problem.  The handle of the previous call is kept and reused when the
         problem structure (ids, observations, constants) is unchanged -- the usual case for the statistics that
         follow every bundle adjustment of the incremental driver -- so only the 7 doubles per pose travel."""
-        import hashlib
-        h = hashlib.blake2b(digest_size=16)
-        for a in (np.asarray(p["cam_ids"], np.int64), np.asarray(p["tag_ids"], np.int64), p["obs_cam"], p["obs_tag"],
-                  p["obs_px"], p["tag_wh"], np.asarray(p["intr"], np.float64), np.asarray(p["dist"], np.float64)):
-            h.update(np.ascontiguousarray(a).tobytes())
-            h.update(b"|")
-        key = (h.hexdigest(), int(p["fixed"]), tuple(sorted(kw.items())))
+        if p.get("key") is not None:
+            key = (p["key"], tuple(sorted(kw.items())))
+        else:
+            import hashlib
+            h = hashlib.blake2b(digest_size=16)
+            for a in (np.asarray(p["cam_ids"], np.int64), np.asarray(p["tag_ids"], np.int64), p["obs_cam"],
+                      p["obs_tag"], p["obs_px"], p["tag_wh"], np.asarray(p["intr"], np.float64),
+                      np.asarray(p["dist"], np.float64)):
+                h.update(np.ascontiguousarray(a).tobytes())
+                h.update(b"|")
+            key = (h.hexdigest(), int(p["fixed"]), tuple(sorted(kw.items())))
         if self._cached is not None and self._cached[0] == key and not os.environ.get("VMM_BA_NO_HANDLE_CACHE"):
             ba = self._cached[1]
             ba.set_state(p["cam_qt"], p["tag_qt"])
+            ba.set_observation_mask(p.get("mask"))
             return ba
         self._drop_cached()
         ba = _engine.BundleAdjuster(p["intr"], p["dist"], p["cam_qt"], p["tag_qt"], p["tag_wh"], p["fixed"],
                                     p["obs_cam"], p["obs_tag"], p["obs_px"], device=self.device, **kw)
+        if p.get("mask") is not None:
+            ba.set_observation_mask(p["mask"])
         self._cached = (key, ba)
         return ba
 
@@ -392,7 +466,7 @@ class TagReconstructor:
                            elimination=_engine.ELIM_AUTO):
         """src/TagReconstructor.cpp:646-743.  Poses are updated in place like the reference's map nodes."""
         p = self._pack(for_ba=True)
-        if len(p["cam_ids"]) == 0 or len(p["tag_ids"]) == 0 or len(p["obs_cam"]) == 0:
+        if len(p["cam_ids"]) == 0 or len(p["tag_ids"]) == 0 or p["n_active"] == 0:
             # Ceres solves an empty problem trivially: CONVERGENCE, nothing changes
             print("Solution %d" % _engine.CONVERGENCE)
             self.lastSummary = {"termination_type": _engine.CONVERGENCE, "iterations": 1}
@@ -407,10 +481,10 @@ class TagReconstructor:
         except Exception:
             self._drop_cached()
             raise
-        for k, cid in enumerate(p["cam_ids"]):
+        for k, cid in zip(p["cam_rows"], p["cam_ids"]):
             self.reconstructedCameras[cid].q = cam[k, :4].copy()
             self.reconstructedCameras[cid].t = cam[k, 4:].copy()
-        for k, tid in enumerate(p["tag_ids"]):
+        for k, tid in zip(p["tag_rows"], p["tag_ids"]):
             self.reconstructedTags[tid].q = tag[k, :4].copy()
             self.reconstructedTags[tid].t = tag[k, 4:].copy()
         self.lastSummary = summary
@@ -426,7 +500,7 @@ class TagReconstructor:
             # covariance report, :761-782 (Eigen prints a row vector with single spaces, 6 significant digits)
             self.lastCovariances = {}
             avg_diag = np.zeros(3)
-            for k, tid in enumerate(p["tag_ids"]):
+            for k, tid in zip(p["tag_rows"], p["tag_ids"]):
                 self.lastCovariances[tid] = cov[k].copy()
                 diag = np.diag(cov[k])
                 std = np.sqrt(diag)
@@ -452,17 +526,19 @@ class TagReconstructor:
     def computeReprojectionErrorPerImg(self):
         """:340-385 -- image id -> mean corner reprojection error; -1.0 for a camera without observations."""
         p, pc, _, _, _ = self._stats(False)
-        return {cid: float(pc[k]) for k, cid in enumerate(p["cam_ids"])}
+        return {cid: float(pc[k]) for k, cid in zip(p["cam_rows"], p["cam_ids"])}
 
     def computeReprojectionErrorPerTag(self):
         """:387-428 -- returns (tag id -> mean error, avg).  The reference returns avg through a reference
         parameter; tags without observations do not appear in the map."""
         p, _, pt, avg, _ = self._stats(False)
-        return {tid: float(pt[k]) for k, tid in enumerate(p["tag_ids"]) if not math.isnan(pt[k])}, float(avg)
+        return {tid: float(pt[k]) for k, tid in zip(p["tag_rows"], p["tag_ids"]) if not math.isnan(pt[k])}, float(avg)
 
     def computeReprojectionErrorPerCorner(self):
         """:430-455 -- list of signed (du, dv) per detected corner, observation order."""
-        _, _, _, _, corner = self._stats(True)
+        p, _, _, _, corner = self._stats(True)
+        if p.get("mask") is not None:
+            corner = corner[p["mask"]]   # resident packing: only the observations of this step
         return [corner.reshape(-1, 2)[i].copy() for i in range(corner.size // 2)]
 
     def removeBadMarkers(self, threshold):
