@@ -39,13 +39,15 @@ __device__ __forceinline__ double block_max(double v, double* sh)
     return r;
 }
 
-// Sums (and maxes) several per-thread values over a 256-thread block with ONE barrier: wave butterflies,
-// then wave 0's lanes combine the four wave totals.  v[0..NS) are summed, v[NS..NS+NM) are maxed; every
-// thread returns with the block totals in v.  Fixed order -> deterministic.
+// Sums (and maxes) several per-thread values over the block with ONE barrier: wave butterflies, then every
+// thread combines the wave totals in a fixed order (pairwise for 4 waves, wave order otherwise).  v[0..NS) are
+// summed, v[NS..NS+NM) are maxed; every thread returns with the block totals in v.  Deterministic.
+// sh: [blockDim.x / 64][NS + NM].
 template <int NS, int NM>
-__device__ __forceinline__ void block_reduce_multi(double (&v)[NS + NM], double* sh /* [4][NS+NM] */)
+__device__ __forceinline__ void block_reduce_multi(double (&v)[NS + NM], double* sh)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
 #pragma unroll
     for (int k = 0; k < NS; ++k)
         v[k] = wave_sum(v[k]);
@@ -61,12 +63,22 @@ __device__ __forceinline__ void block_reduce_multi(double (&v)[NS + NM], double*
             sh[wave * (NS + NM) + k] = v[k];
     }
     __syncthreads();
+    if (nw == 4) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k)
-        v[k] = (sh[k] + sh[(NS + NM) + k]) + (sh[2 * (NS + NM) + k] + sh[3 * (NS + NM) + k]);
+        for (int k = 0; k < NS; ++k)
+            v[k] = (sh[k] + sh[(NS + NM) + k]) + (sh[2 * (NS + NM) + k] + sh[3 * (NS + NM) + k]);
 #pragma unroll
-    for (int k = NS; k < NS + NM; ++k)
-        v[k] = fmax(fmax(sh[k], sh[(NS + NM) + k]), fmax(sh[2 * (NS + NM) + k], sh[3 * (NS + NM) + k]));
+        for (int k = NS; k < NS + NM; ++k)
+            v[k] = fmax(fmax(sh[k], sh[(NS + NM) + k]), fmax(sh[2 * (NS + NM) + k], sh[3 * (NS + NM) + k]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS + NM; ++k) {
+            double r = sh[k];
+            for (int w = 1; w < nw; ++w)
+                r = (k < NS) ? r + sh[w * (NS + NM) + k] : fmax(r, sh[w * (NS + NM) + k]);
+            v[k] = r;
+        }
+    }
     __syncthreads();
 }
 
@@ -91,7 +103,7 @@ __device__ __forceinline__ double* pose_ptr(const PoseViews& v, int p, bool cand
 //      max-norm |Plus(x,-g) - x|_inf, completion of the pending iteration record;
 //  (b) FinalizeIterationAndCheckIfMinimizerCanContinue: push the record, termination tests;
 //  (c) first half of LevenbergMarquardtStrategy::ComputeStep: the LM diagonal D^2.
-__global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, const double* __restrict__ src,
+__global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, const double* __restrict__ src,
                                                     double* __restrict__ dst, size_t small_count,
                                                     const double* __restrict__ H, const double* __restrict__ g,
                                                     const double* __restrict__ cost_slot,
@@ -114,14 +126,14 @@ __global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, co
     if (ctl->need_jacobian) {
         // multi-GPU: the all-reduced staging buffer becomes the working copy
         if (src != dst) {
-            for (size_t i = tid; i < small_count; i += 256)
+            for (size_t i = tid; i < small_count; i += blockDim.x)
                 dst[i] = src[i];
             __syncthreads();
         }
         const bool first = ctl->first_eval != 0;
         const bool jacobi = ctl->jacobi_scaling != 0;
         double xn = 0.0, gm = 0.0, cst = 0.0;
-        for (int p = tid; p < n_pose; p += 256) {
+        for (int p = tid; p < n_pose; p += (int)blockDim.x) {
             const double* Hp = H + 36 * (int64_t)p;
             if (first) {
                 // blocks with zero Jacobian columns (constant origin tag, poses without observations)
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, co
         }
         // single GPU: per-pose costs of the eliminated family are summed here; world > 1: cost_slot
         if (pose_cost)
-            for (int i = tid; i < n_pose_cost; i += 256)
+            for (int i = tid; i < n_pose_cost; i += (int)blockDim.x)
                 cst += pose_cost[i];
         double red[3] = { xn, cst, gm };
         block_reduce_multi<2, 1>(red, sh);
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(256) void k_iter_begin(LmCtl* ctl, PoseViews pv, co
     if (s_stop)
         return;
     const double lo = s_lo, hi = s_hi;
-    for (int c = tid; c < n_tan; c += 256) {
+    for (int c = tid; c < n_tan; c += (int)blockDim.x) {
         double d;
         if (!s_reuse) {
             const int p = c / 6, k = c % 6;
@@ -525,7 +537,7 @@ void launch_zero_unless_eval(Engine& e, double* buf, size_t n)
 void launch_iter_begin(Engine& e, const double* src)
 {
     const bool single = !e.multi;
-    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), src, e.small, e.small_count,
+    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1024), 0, e.stream, e.ctl, views(e), src, e.small, e.small_count,
                        e.H_cam, e.g_cam, e.cost_slot, single ? e.part_cost : (const double*)nullptr, e.n_e, e.scale,
                        e.active, e.diag, e.D2, e.trace);
 }
