@@ -195,6 +195,13 @@ def main():
         line["roofline"] = {"kernel": names.get(dom, dom), "bound": d["bound"], "achieved": d["achieved"],
                             "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": traffic.get(dom),
                             "avg_launch_ms": d["ms"]}
+        if dom == "cholesky_solve":
+            # the group is a chain of launches; rocprofv3's per-kernel averages (profiles/) are per launch
+            nb = (n_red + 63) // 64
+            line["roofline"]["launches"] = {"k_chol_step": nb, "k_backsolve_chain": 1}
+            line["roofline"]["note"] = ("avg_launch_ms, achieved and traffic are for one whole factorisation + solve "
+                                        "(the %d launches above, back to back); bound by the %d dependent pivots, "
+                                        "not by the matrix cores (DESIGN.md section 4)" % (nb + 1, n_red))
         line["kernels"] = {k: {"ms": v["ms"], "bound": v["bound"], "achieved": v["achieved"],
                                "unit": v["unit"], "frac": v["frac"], "traffic": traffic.get(k)}
                            for k, v in kern.items()}
