@@ -211,5 +211,174 @@ std::array<double, 2> projectPoint(const CamModel& cm, double X, double Y, doubl
     return { uv[0], uv[1] };
 }
 
+// Device-resident variant for the incremental driver (startReconstruction, src/TagReconstructor.cpp:86-278): ONE
+// handle is built from the whole detection result and kept as a member of the reconstructor; every bundle
+// adjustment and every statistics call of the run only sends the poses and a mask over the observations
+// (camera and tag both reconstructed, :699-708) -- vmm_ba_set_observation_mask.  Same results as the functions
+// above, without a vmm_ba_create per call.  Detection needs .images[].imageId, .tags[].{tagId,width,height},
+// .tagObservations[].{imageId,tagId,corners}.
+template <class Detection, class CamModel>
+class Resident {
+public:
+    Resident(const Detection& det, const CamModel& cm, int device = 0) : device_(device)
+    {
+        std::map<int, int> ci, ti;
+        for (const auto& im : det.images) ci[im.imageId] = 0;
+        for (const auto& ob : det.tagObservations) ci[ob.imageId] = 0;
+        for (const auto& t : det.tags) ti[t.tagId] = 0;
+        for (const auto& ob : det.tagObservations) ti[ob.tagId] = 0;
+        for (auto& kv : ci) { kv.second = (int)cam_ids_.size(); cam_ids_.push_back(kv.first); }
+        for (auto& kv : ti) { kv.second = (int)tag_ids_.size(); tag_ids_.push_back(kv.first); }
+        cam_index_ = ci;
+        tag_index_ = ti;
+        tag_wh_.assign(2 * tag_ids_.size(), 1.0);
+        for (const auto& t : det.tags) {
+            tag_wh_[2 * ti[t.tagId]] = t.width;
+            tag_wh_[2 * ti[t.tagId] + 1] = t.height;
+        }
+        for (const auto& ob : det.tagObservations) {
+            obs_img_.push_back(ob.imageId);
+            obs_tagid_.push_back(ob.tagId);
+            obs_cam_.push_back(ci[ob.imageId]);
+            obs_tag_.push_back(ti[ob.tagId]);
+            for (int k = 0; k < 4; ++k) {
+                obs_px_.push_back(ob.corners[k].x());
+                obs_px_.push_back(ob.corners[k].y());
+            }
+        }
+        intr_[0] = cm.fx; intr_[1] = cm.fy; intr_[2] = cm.cx; intr_[3] = cm.cy;
+        for (int i = 0; i < 5; ++i) dist_[i] = cm.distortionCoefficients(i, 0);
+    }
+    ~Resident() { if (h_) vmm_ba_destroy(h_); }
+    Resident(const Resident&) = delete;
+    Resident& operator=(const Resident&) = delete;
+
+    // doBundleAdjustment on the current maps; returns the termination type and prints like the free function
+    template <class TagMap, class CamMap>
+    int doBundleAdjustment(TagMap& tags, CamMap& cams, int originTagId, int maxNumIterations, size_t ceresThreads,
+                           bool robustify = true)
+    {
+        if (!prepare(tags, cams, originTagId, true)) {
+            std::cout << "Solution " << VMM_BA_CONVERGENCE << std::endl;
+            return VMM_BA_CONVERGENCE;
+        }
+        vmm_ba_options o;
+        vmm_ba_default_options(&o);
+        o.max_num_iterations = maxNumIterations;
+        o.num_threads = (int32_t)ceresThreads;
+        o.robustify = robustify ? 1 : 0;
+        vmm_ba_summary s;
+        s.trace = nullptr;
+        s.trace_capacity = 0;
+        check(vmm_ba_solve(h_, &o, &s), "vmm_ba_solve");
+        check(vmm_ba_get_state(h_, cam_qt_.data(), tag_qt_.data()), "vmm_ba_get_state");
+        for (auto& kv : cams) {
+            if (!cam_active_[cam_index_[kv.first]]) continue;         // :689-690 cameras without reconstructed tags
+            const double* q = &cam_qt_[7 * cam_index_[kv.first]];
+            for (int i = 0; i < 4; ++i) kv.second.q(i) = q[i];
+            for (int i = 0; i < 3; ++i) kv.second.t(i) = q[4 + i];
+        }
+        for (auto& kv : tags) {
+            const double* q = &tag_qt_[7 * tag_index_[kv.first]];
+            for (int i = 0; i < 4; ++i) kv.second.q(i) = q[i];
+            for (int i = 0; i < 3; ++i) kv.second.t(i) = q[4 + i];
+        }
+        std::cout << "Solution " << s.termination_type << std::endl;  // :740
+        return s.termination_type;
+    }
+
+    template <class TagMap, class CamMap>
+    Stats reprojectionStatistics(const TagMap& tags, const CamMap& cams, int originTagId, bool want_corners)
+    {
+        Stats out;
+        if (tags.empty() || cams.empty())
+            return out;
+        prepare(tags, cams, originTagId, false);
+        std::vector<double> pc(cam_ids_.size()), pt(tag_ids_.size()), corner(want_corners ? obs_px_.size() : 0);
+        check(vmm_ba_reprojection_stats(h_, pc.data(), pt.data(), &out.avg, want_corners ? corner.data() : nullptr),
+              "vmm_ba_reprojection_stats");
+        for (const auto& kv : cams)
+            out.per_img[kv.first] = pc[cam_index_[kv.first]];         // -1.0 for cameras without observations
+        for (const auto& kv : tags)
+            if (!std::isnan(pt[tag_index_[kv.first]]))
+                out.per_tag[kv.first] = pt[tag_index_[kv.first]];
+        for (size_t i = 0; i < mask_.size() && want_corners; ++i)
+            if (mask_[i])
+                for (int k = 0; k < 4; ++k)
+                    out.per_corner.push_back({ corner[8 * i + 2 * k], corner[8 * i + 2 * k + 1] });
+        return out;
+    }
+
+private:
+    // state + mask of this step; (re)creates the handle when the constant block changes.  false: nothing to solve
+    template <class TagMap, class CamMap>
+    bool prepare(const TagMap& tags, const CamMap& cams, int originTagId, bool for_ba)
+    {
+        cam_qt_.assign(7 * cam_ids_.size(), 0.0);
+        tag_qt_.assign(7 * tag_ids_.size(), 0.0);
+        for (size_t c = 0; c < cam_ids_.size(); ++c) { cam_qt_[7 * c] = 1.0; cam_qt_[7 * c + 6] = 1.0; }   // finite defaults
+        for (size_t t = 0; t < tag_ids_.size(); ++t) tag_qt_[7 * t] = 1.0;
+        for (const auto& kv : cams) {
+            double* q = &cam_qt_[7 * cam_index_.at(kv.first)];
+            for (int i = 0; i < 4; ++i) q[i] = kv.second.q(i);
+            for (int i = 0; i < 3; ++i) q[4 + i] = kv.second.t(i);
+        }
+        for (const auto& kv : tags) {
+            double* q = &tag_qt_[7 * tag_index_.at(kv.first)];
+            for (int i = 0; i < 4; ++i) q[i] = kv.second.q(i);
+            for (int i = 0; i < 3; ++i) q[4 + i] = kv.second.t(i);
+        }
+        mask_.assign(obs_cam_.size(), 0);
+        cam_active_.assign(cam_ids_.size(), 0);
+        size_t n_on = 0;
+        for (size_t i = 0; i < obs_cam_.size(); ++i)
+            if (cams.count(obs_img_[i]) && tags.count(obs_tagid_[i])) {
+                mask_[i] = 1;
+                cam_active_[obs_cam_[i]] = 1;
+                ++n_on;
+            }
+        const auto o = tags.count(originTagId) ? tag_index_.find(originTagId) : tag_index_.end();
+        const int fixed = (o == tag_index_.end()) ? -1 : o->second;
+        if (for_ba && n_on == 0)
+            return false;
+        if (!h_ || fixed != fixed_) {
+            if (h_) vmm_ba_destroy(h_);
+            h_ = nullptr;
+            vmm_ba_problem q;
+            for (int i = 0; i < 4; ++i) q.intr[i] = intr_[i];
+            for (int i = 0; i < 5; ++i) q.dist[i] = dist_[i];
+            q.n_cams = (int32_t)cam_ids_.size();
+            q.n_tags = (int32_t)tag_ids_.size();
+            q.cam_qt = cam_qt_.data();
+            q.tag_qt = tag_qt_.data();
+            q.tag_wh = tag_wh_.data();
+            q.fixed_tag = fixed;
+            q.n_obs = (int64_t)obs_cam_.size();
+            q.obs_cam = obs_cam_.data();
+            q.obs_tag = obs_tag_.data();
+            q.obs_px = obs_px_.data();
+            vmm_ba_create_options co;
+            vmm_ba_default_create_options(&co);
+            co.device = device_;
+            check(vmm_ba_create(&q, &co, &h_), "vmm_ba_create");
+            fixed_ = fixed;
+        } else {
+            check(vmm_ba_set_state(h_, cam_qt_.data(), tag_qt_.data()), "vmm_ba_set_state");
+        }
+        check(vmm_ba_set_observation_mask(h_, mask_.data()), "vmm_ba_set_observation_mask");
+        return true;
+    }
+
+    int device_;
+    vmm_ba_handle h_ = nullptr;
+    int fixed_ = -2;
+    std::vector<int> cam_ids_, tag_ids_, obs_img_, obs_tagid_;
+    std::map<int, int> cam_index_, tag_index_;
+    std::vector<double> tag_wh_, obs_px_, cam_qt_, tag_qt_;
+    std::vector<int32_t> obs_cam_, obs_tag_;
+    std::vector<uint8_t> mask_, cam_active_;
+    double intr_[4], dist_[5];
+};
+
 } // namespace vmm_ba_adapter
 #endif

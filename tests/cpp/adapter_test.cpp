@@ -2,7 +2,10 @@
 // Eigen-based types (q(i), t(i), corners[k].x(), distortionCoefficients(i,0)); this image has no Eigen.
 // Reads a flat scene from stdin, runs doBundleAdjustment + statistics on the GPU, prints the result.
 // Usage: adapter_test < scene.txt   (see tests/test_gpu_cpp_adapter.py)
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
+#include <iterator>
 #include <iostream>
 #include <map>
 #include <vector>
@@ -16,7 +19,9 @@ struct Vec5 { double v[5]; double operator()(int i, int) const { return v[i]; } 
 struct Camera { int cameraId = -1; Vec4 q{{1, 0, 0, 0}}; Vec3 t{{0, 0, 0}}; };
 struct ReconstructedTag { int id = -1; std::string tagType; Vec4 q{{1, 0, 0, 0}}; Vec3 t{{0, 0, 0}}; double tagWidth = 0, tagHeight = 0; };
 struct TagObservation { int imageId = -1, tagId = -1; std::vector<Vec2> corners; };
-struct DetectionResult { std::vector<TagObservation> tagObservations; };
+struct TagImg { int imageId = -1; };
+struct Tag { int tagId = -1; double width = 0, height = 0; };
+struct DetectionResult { std::vector<TagImg> images; std::vector<Tag> tags; std::vector<TagObservation> tagObservations; };
 struct CameraModel { double fx, fy, cx, cy; Vec5 distortionCoefficients; int verticalResolution, horizontalResolution; };
 
 int main()
@@ -48,7 +53,35 @@ int main()
         for (auto& c : ob.corners) if (scanf("%lf %lf", &c.v[0], &c.v[1]) != 2) return 2;
         det.tagObservations.push_back(ob);
     }
+    for (const auto& kv : cams) { TagImg im; im.imageId = kv.first; det.images.push_back(im); }
+    for (const auto& kv : tags) { Tag t; t.tagId = kv.first; t.width = kv.second.tagWidth; t.height = kv.second.tagHeight; det.tags.push_back(t); }
+    const std::map<int, Camera> cams0 = cams;
+    const std::map<int, ReconstructedTag> tags0 = tags;
     try {
+        {
+            // device-resident handle (one vmm_ba_create for the whole detection set, masks per step) against the
+            // free functions on a sub-problem: the last camera and the last tag are not reconstructed yet
+            std::map<int, Camera> ca = cams0, cb = cams0;
+            std::map<int, ReconstructedTag> ta = tags0, tb = tags0;
+            ca.erase(std::prev(ca.end())); cb.erase(std::prev(cb.end()));
+            ta.erase(std::prev(ta.end())); tb.erase(std::prev(tb.end()));
+            vmm_ba_adapter::Resident<DetectionResult, CameraModel> res(det, cm);
+            res.doBundleAdjustment(ta, ca, origin, 400, 1, true);
+            vmm_ba_adapter::doBundleAdjustment(tb, cb, det, cm, origin, 400, 1, true, false);
+            double md = 0.0;
+            for (const auto& kv : ca) { for (int i = 0; i < 4; ++i) md = std::max(md, std::fabs(kv.second.q(i) - cb.at(kv.first).q(i))); for (int i = 0; i < 3; ++i) md = std::max(md, std::fabs(kv.second.t(i) - cb.at(kv.first).t(i))); }
+            for (const auto& kv : ta) { for (int i = 0; i < 4; ++i) md = std::max(md, std::fabs(kv.second.q(i) - tb.at(kv.first).q(i))); for (int i = 0; i < 3; ++i) md = std::max(md, std::fabs(kv.second.t(i) - tb.at(kv.first).t(i))); }
+            const auto sa = res.reprojectionStatistics(ta, ca, origin, true);
+            const auto sb = vmm_ba_adapter::reprojectionStatistics(tb, cb, det, cm, true);
+            double sd = std::fabs(sa.avg - sb.avg);
+            for (const auto& kv : sb.per_img) sd = std::max(sd, std::fabs(kv.second - sa.per_img.at(kv.first)));
+            for (const auto& kv : sb.per_tag) sd = std::max(sd, std::fabs(kv.second - sa.per_tag.at(kv.first)));
+            // grow by the camera and tag left out, like the next step of the driver: same handle, new mask
+            ca = cams0; ta = tags0;
+            res.doBundleAdjustment(ta, ca, origin, 400, 1, true);
+            printf("RESIDENT_MAXDIFF %.3e STATSDIFF %.3e NCORNER %zu %zu\n", md, sd, sa.per_corner.size(), sb.per_corner.size());
+            for (const auto& kv : ta) { printf("RTAG %d", kv.first); for (double d : kv.second.q.v) printf(" %.17g", d); for (double d : kv.second.t.v) printf(" %.17g", d); printf("\n"); }
+        }
         const int term = vmm_ba_adapter::doBundleAdjustment(tags, cams, det, cm, origin, 400, 1, true, true);
         const auto st = vmm_ba_adapter::reprojectionStatistics(tags, cams, det, cm, true);
         const auto uv = vmm_ba_adapter::projectPoint(cm, 0.3, -0.2, 2.5);

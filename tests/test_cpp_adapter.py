@@ -52,9 +52,15 @@ def test_adapter_matches_python_engine():
     r = subprocess.run([EXE], input=_scene_text(s, tag_ids, cam_ids), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "Solution 0" in r.stdout
-    cams, tags, avg, stddev, rms = {}, {}, None, {}, None
+    cams, tags, avg, stddev, rms, rtags, resident = {}, {}, None, {}, None, {}, None
     for line in r.stdout.splitlines():
         f = line.split()
+        if f[0] == "RESIDENT_MAXDIFF":
+            resident = (float(f[1]), float(f[3]), int(f[5]), int(f[6]))
+            continue
+        if f[0] == "RTAG":
+            rtags[int(f[1])] = np.array(f[2:], float)
+            continue
         if line.startswith("StdDev of tag"):           # src/TagReconstructor.cpp:771-772
             stddev[int(f[3].rstrip(":"))] = np.array(f[4:7], float)
         elif line.startswith("Marker Position RMS ="):   # :781
@@ -75,6 +81,10 @@ def test_adapter_matches_python_engine():
     for k, t in enumerate(tag_ids):                     # default ostream precision: 6 significant digits
         np.testing.assert_allclose(stddev[t], np.sqrt(np.diag(cov[k])), rtol=6e-6, atol=0)
     np.testing.assert_allclose(rms, np.sqrt(np.trace(cov.sum(axis=0)) / len(tag_ids)), rtol=6e-6)
+    # vmm_ba_adapter::Resident (one handle + observation masks) == the free functions on the sub-problem, and
+    # after growing to the full problem == the full solve
+    assert resident is not None and resident[0] < 1e-9 and resident[1] < 1e-9 and resident[2] == resident[3] > 0
+    np.testing.assert_allclose(np.array([rtags[t] for t in tag_ids]), tag, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(np.array([cams[c] for c in cam_ids]), cam)   # same library, same bits
     np.testing.assert_array_equal(np.array([tags[t] for t in tag_ids]), tag)
     assert avg == ref_avg and ncorner == 4 * s.n_obs
