@@ -65,8 +65,9 @@ struct LmCtl {
 
 // Stream-K decomposition of the rank-k update (kernels_schur.hip): device arrays + sizes.
 struct SyrkPlan {
-    int n_tiles = 0, n_kt = 0, n_wg = 0, units_per_wg = 0, n_segments = 0;
+    int n_tiles = 0, n_kt = 0, n_wg = 0, n_segments = 0;
     int32_t *tile_bi = nullptr, *tile_bj = nullptr, *wg_seg0 = nullptr, *tile_seg0 = nullptr;
+    int64_t *wg_u0 = nullptr, *wg_u1 = nullptr;   // [n_wg] unit range of each workgroup (by blockIdx)
     double* partials = nullptr;   // [n_segments][kST*kST]
 };
 

@@ -151,11 +151,16 @@ __global__ __launch_bounds__(256) void k_form_z(const LmCtl* ctl, int64_t n_obs,
 // was 575 MB per launch at 500x200 (PMC FETCH_SIZE; 5.2 TB/s over the 111 us launch -- bandwidth-bound
 // at 8 flop/B); 128x128 tiles double the intensity to 16 flop/B and halve the traffic.
 //
-// Work decomposition ("stream-K"): the unit of work is one K tile (16 rows of Z) of one output tile.
-// All units, ordered tile-major, are cut into equal contiguous ranges, one per workgroup, so every
-// workgroup issues the same number of MFMAs whatever the tile count (55 tiles on 256 CUs quantise badly
-// with a fixed K split).  A workgroup writes one 128x128 partial per (tile) segment of its range;
-// k_reduce_partials sums a tile's partials in segment order -- deterministic, no atomics.
+// Work decomposition: the unit of work is one K stage (16 rows of Z) of one output tile; every workgroup
+// gets a contiguous range of units and its first segment id by blockIdx (host plan, make_syrk_plan):
+//   * few tiles (500 x 200: 55 tiles on 512 workgroup slots): "stream-K" -- all units, tile-major, cut into
+//     equal ranges, so every workgroup issues the same number of MFMAs whatever the tile count;
+//   * more tiles than slots (2000 x 1000: 1128): whole rounds of one tile per workgroup, ordered so that the
+//     64 workgroups resident on one XCD (blockIdx % 8) hold 64 consecutive tiles of the row-major list and
+//     share their operand panels through that XCD's L2 (PMC FETCH_SIZE: 28.0 -> 12.4 GB per launch), then
+//     stream-K for the leftover tiles.
+// A workgroup writes one 128x128 partial per (tile) segment of its range; k_reduce_partials sums a tile's
+// partials in segment order -- deterministic, no atomics.
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -165,10 +170,12 @@ constexpr int kSyrkRow = 144;       // LDS row stride (doubles) of a 128-wide st
 constexpr int kSyrkTile = kSyrkT * kSyrkT;
 
 struct SyrkPlanDev {
-    int n_tiles, n_kt, n_wg, units_per_wg;
+    int n_tiles, n_kt, n_wg;
     const int32_t* tile_bi;     // [n_tiles] in units of 128 rows
     const int32_t* tile_bj;     // [n_tiles]
-    const int32_t* wg_seg0;     // [n_wg + 1] first segment id of each workgroup
+    const int64_t* wg_u0;       // [n_wg] first unit of each workgroup (by blockIdx)
+    const int64_t* wg_u1;       // [n_wg] one past its last unit
+    const int32_t* wg_seg0;     // [n_wg] first segment id of each workgroup
     const int32_t* tile_seg0;   // [n_tiles + 1] first segment id of each tile
     double* partials;           // [n_segments][128*128]
 };
@@ -181,9 +188,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_streamk(const LmCtl* ctl, const
     __shared__ __attribute__((aligned(16))) double As[2][kSyrkKT * kSyrkRow];
     __shared__ __attribute__((aligned(16))) double Bs[2][kSyrkKT * kSyrkRow];
     const int g = blockIdx.x;
-    const int64_t units = (int64_t)pl.n_tiles * pl.n_kt;
-    int64_t u = (int64_t)g * pl.units_per_wg;
-    const int64_t u_end = (u + pl.units_per_wg < units) ? u + pl.units_per_wg : units;
+    int64_t u = pl.wg_u0[g];
+    const int64_t u_end = pl.wg_u1[g];
     int seg = pl.wg_seg0[g];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -362,9 +368,10 @@ static SyrkPlanDev plan_dev(const SyrkPlan& p)
     d.n_tiles = p.n_tiles;
     d.n_kt = p.n_kt;
     d.n_wg = p.n_wg;
-    d.units_per_wg = p.units_per_wg;
     d.tile_bi = p.tile_bi;
     d.tile_bj = p.tile_bj;
+    d.wg_u0 = p.wg_u0;
+    d.wg_u1 = p.wg_u1;
     d.wg_seg0 = p.wg_seg0;
     d.tile_seg0 = p.tile_seg0;
     d.partials = p.partials;

@@ -108,8 +108,18 @@ static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx
     return VMM_BA_OK;
 }
 
-// Stream-K plan: lower 128x128 tiles with row blocks 0..n_row_blk-1 and column blocks 0..n_col_blk-1
-// (bj <= bi), K tiles of 16 rows; all (tile, K tile) units are cut into equal contiguous ranges.
+// Work plan of the rank-k update: lower 128x128 tiles with row blocks 0..n_row_blk-1 and column blocks
+// 0..n_col_blk-1 (bj <= bi), K stages of 16 rows; the unit of work is one K stage of one tile.
+//   * Fewer tiles than workgroup slots (500 x 200: 55 tiles, 512 slots): "stream-K" -- all units, tile-major,
+//     are cut into equal contiguous ranges, one per workgroup.
+//   * More tiles than slots (2000 x 1000: 1128 tiles): whole rounds of one-tile-per-workgroup first, XCD-aware:
+//     workgroup b runs on XCD b % 8, so the 64 workgroups an XCD holds at a time get 64 CONSECUTIVE tiles of
+//     the row-major tile list -- one or two block rows -- and sweep K in step: the A panel of a block row and
+//     the B panels of its columns are fetched into that XCD's L2 once per K stage and shared (with the plain
+//     stream-K order every workgroup streams its own two panels from HBM: 16 flop/B, measured HBM-bound at
+//     63 TFLOP/s).  The tiles left over after the last full round are split stream-K over one more round.
+// Every workgroup gets its unit range and first segment id by blockIdx; segments (one partial tile each) are
+// numbered in unit order, so a tile's partials are consecutive and summed in that order.
 static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, int k_pad)
 {
     std::vector<int32_t> bi, bj;
@@ -120,8 +130,7 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
         }
     p.n_tiles = (int)bi.size();
     p.n_kt = k_pad / kKT;
-    const int64_t units = (int64_t)p.n_tiles * p.n_kt;
-    // two workgroups (72 KB of LDS each) per CU; for larger problems whole multiples of that keep the tail short
+    // two workgroups (72 KB of LDS each) per CU
     int hw = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, e.device) == hipSuccess)
@@ -132,18 +141,29 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
     if (const char* v = getenv("VMM_BA_SYRK_WG_PER_CU"))
         per_cu = std::max(1, atoi(v));
     const int64_t slots = per_cu * (int64_t)hw;
-    int64_t n_wg = std::min<int64_t>(units, slots);
-    if (units > 64 * slots)
-        n_wg = 4 * slots;   // plenty of K tiles per workgroup: several waves of workgroups balance the chip
-    p.units_per_wg = (int)((units + n_wg - 1) / std::max<int64_t>(n_wg, 1));
-    p.n_wg = p.units_per_wg > 0 ? (int)((units + p.units_per_wg - 1) / p.units_per_wg) : 0;
-    std::vector<int32_t> wg_seg0((size_t)p.n_wg + 1, 0), tile_seg0((size_t)p.n_tiles + 1, 0);
-    // segments in unit order: cut at tile boundaries and at workgroup boundaries
+    const bool xcd_rounds = !(getenv("VMM_BA_SYRK_NO_XCD") && getenv("VMM_BA_SYRK_NO_XCD")[0] == '1');
+    const int n_xcd = 8;
+    const int64_t full_rounds = (xcd_rounds && slots % n_xcd == 0) ? p.n_tiles / slots : 0;
+    const int64_t tiles_a = full_rounds * slots;                      // one tile per workgroup
+    const int64_t units_b = (int64_t)(p.n_tiles - tiles_a) * p.n_kt;  // the rest: stream-K
+    int64_t n_wg_b = std::min<int64_t>(units_b, slots);
+    if (full_rounds == 0 && units_b > 64 * slots)
+        n_wg_b = 4 * slots;   // xcd_rounds switched off: several waves of stream-K workgroups
+    const int64_t upw_b = n_wg_b > 0 ? (units_b + n_wg_b - 1) / n_wg_b : 0;
+    n_wg_b = upw_b > 0 ? (units_b + upw_b - 1) / upw_b : 0;
+    p.n_wg = (int)(tiles_a + n_wg_b);
+    // logical workgroup l (unit order) -> [u0, u1); segments numbered in unit order
+    std::vector<int64_t> lu0((size_t)p.n_wg + 1, 0);
+    for (int64_t l = 0; l < tiles_a; ++l)
+        lu0[(size_t)l] = l * p.n_kt;
+    for (int64_t l = 0; l <= n_wg_b; ++l)
+        lu0[(size_t)(tiles_a + l)] = std::min<int64_t>(tiles_a * p.n_kt + l * upw_b, (int64_t)p.n_tiles * p.n_kt);
+    std::vector<int32_t> lseg0((size_t)p.n_wg + 1, 0), tile_seg0((size_t)p.n_tiles + 1, 0);
     int seg = 0;
-    for (int g = 0; g < p.n_wg; ++g) {
-        wg_seg0[g] = seg;
-        int64_t u = (int64_t)g * p.units_per_wg;
-        const int64_t u_end = std::min<int64_t>(units, u + p.units_per_wg);
+    for (int l = 0; l < p.n_wg; ++l) {
+        lseg0[l] = seg;
+        int64_t u = lu0[l];
+        const int64_t u_end = lu0[l + 1];
         while (u < u_end) {
             const int t = (int)(u / p.n_kt);
             const int kt0 = (int)(u % p.n_kt);
@@ -154,17 +174,33 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
             ++seg;
         }
     }
-    wg_seg0[p.n_wg] = seg;
     tile_seg0[p.n_tiles] = seg;
     p.n_segments = seg;
+    // blockIdx -> logical workgroup: inside a full round, XCD x (blockIdx % 8) takes the x-th run of slots/8 tiles
+    std::vector<int64_t> wg_u0((size_t)p.n_wg), wg_u1((size_t)p.n_wg);
+    std::vector<int32_t> wg_seg0((size_t)p.n_wg);
+    for (int b = 0; b < p.n_wg; ++b) {
+        int64_t l = b;
+        if (b < tiles_a) {
+            const int64_t r = b / slots, o = b % slots;
+            l = r * slots + (o % n_xcd) * (slots / n_xcd) + o / n_xcd;
+        }
+        wg_u0[b] = lu0[(size_t)l];
+        wg_u1[b] = lu0[(size_t)l + 1];
+        wg_seg0[b] = lseg0[(size_t)l];
+    }
     int rc;
     if ((rc = dev_alloc(e, &p.tile_bi, bi.size()))) return rc;
     if ((rc = dev_alloc(e, &p.tile_bj, bj.size()))) return rc;
+    if ((rc = dev_alloc(e, &p.wg_u0, wg_u0.size()))) return rc;
+    if ((rc = dev_alloc(e, &p.wg_u1, wg_u1.size()))) return rc;
     if ((rc = dev_alloc(e, &p.wg_seg0, wg_seg0.size()))) return rc;
     if ((rc = dev_alloc(e, &p.tile_seg0, tile_seg0.size()))) return rc;
     if ((rc = dev_alloc(e, &p.partials, (size_t)std::max(seg, 1) * kST * kST, false))) return rc;
     if ((rc = upload(e, p.tile_bi, bi))) return rc;
     if ((rc = upload(e, p.tile_bj, bj))) return rc;
+    if ((rc = upload(e, p.wg_u0, wg_u0))) return rc;
+    if ((rc = upload(e, p.wg_u1, wg_u1))) return rc;
     if ((rc = upload(e, p.wg_seg0, wg_seg0))) return rc;
     if ((rc = upload(e, p.tile_seg0, tile_seg0))) return rc;
     HIP_TRY(hipStreamSynchronize(e.stream));
