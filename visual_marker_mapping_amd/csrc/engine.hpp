@@ -144,6 +144,7 @@ struct Engine {
 
     // one LM iteration captured as a hipGraph (single GPU; collectives are host calls)
     hipGraphExec_t iter_graph = nullptr;
+    hipGraphExec_t iter_graph_seg[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };   // world > 1: the groups between the all-reduces
     int graph_robustify = -1;
     double graph_huber_a = 0.0;
     bool use_graph = true;

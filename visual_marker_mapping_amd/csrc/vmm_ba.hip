@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "engine.hpp"
@@ -240,6 +241,9 @@ static void destroy_engine(Engine* e)
         (void)hipStreamSynchronize(e->stream);
     if (e->iter_graph)
         (void)hipGraphExecDestroy(e->iter_graph);
+    for (auto& g : e->iter_graph_seg)
+        if (g)
+            (void)hipGraphExecDestroy(g);
     for (void* p : e->allocs)
         (void)hipFree(p);
     if (e->ctl_host)
@@ -250,43 +254,103 @@ static void destroy_engine(Engine* e)
 }
 
 // One LM iteration as a fixed sequence of guarded kernels (+ all-reduces when world > 1).
+// One LM iteration = five groups of guarded kernels separated (world > 1) by the four sum-all-reduces.
+static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg)
+{
+    switch (seg) {
+    case 0:
+        launch_eval_passes(e, true, o.robustify, o.huber_a, true);
+        if (e.multi)
+            launch_zero_unless_eval(e, e.small_stage, e.small_count);
+        break;
+    case 1:
+        launch_iter_begin(e, e.multi ? e.small_stage : e.small);
+        launch_elim(e);
+        launch_syrk_reduced(e);
+        break;
+    case 2:
+        launch_add_diag(e);
+        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
+        launch_backsub(e);
+        if (e.multi)
+            launch_sum(e, true, e.part_cross, e.n_e, e.step_comm + 6 * (size_t)e.n_e);
+        break;
+    case 3:
+        launch_candidate(e);
+        if (e.multi)
+            launch_cost(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a, e.cost_comm);
+        else
+            launch_cost_kernel(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a);   // summed by k_decide
+        break;
+    default:
+        launch_decide(e);
+        break;
+    }
+}
+
+// the all-reduce that follows segment `seg` when world > 1 (none after the last one)
+static int allreduce_after(Engine& e, int seg)
+{
+    switch (seg) {
+    case 0: return do_allreduce(e, e.small_stage, e.small_count);
+    case 1: return do_allreduce(e, e.S, (size_t)(e.n_pad + 1) * e.ldz);
+    case 2: return do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1);
+    case 3: return do_allreduce(e, e.cost_comm, 1);
+    default: return VMM_BA_OK;
+    }
+}
+
 static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
 {
     int rc;
-    launch_eval_passes(e, true, o.robustify, o.huber_a, true);
-    if (e.multi) {
-        launch_zero_unless_eval(e, e.small_stage, e.small_count);
-        if ((rc = do_allreduce(e, e.small_stage, e.small_count))) return rc;
+    for (int seg = 0; seg < 5; ++seg) {
+        enqueue_segment(e, o, seg);
+        if (e.multi && (rc = allreduce_after(e, seg)))
+            return rc;
     }
-    launch_iter_begin(e, e.multi ? e.small_stage : e.small);
-    launch_elim(e);
-    launch_syrk_reduced(e);
-    if ((rc = do_allreduce(e, e.S, (size_t)(e.n_pad + 1) * e.ldz))) return rc;
-    launch_add_diag(e);
-    launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
-    launch_backsub(e);
-    if (e.multi) {
-        launch_sum(e, true, e.part_cross, e.n_e, e.step_comm + 6 * (size_t)e.n_e);
-        if ((rc = do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1))) return rc;
-    }
-    launch_candidate(e);
-    if (e.multi) {
-        launch_cost(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a, e.cost_comm);
-        if ((rc = do_allreduce(e, e.cost_comm, 1))) return rc;
-    } else {
-        launch_cost_kernel(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a);   // summed by k_decide
-    }
-    launch_decide(e);
     HIP_TRY(hipGetLastError());
     return VMM_BA_OK;
 }
 
-// Single GPU: the iteration is captured once into a hipGraph and replayed (about 75 small launches;
-// eager enqueueing is host-bound).  With world > 1 the all-reduce callbacks are host calls, so the
-// sequence is enqueued eagerly.
+static int capture_graph(Engine& e, hipGraphExec_t* out, const std::function<void()>& body)
+{
+    hipGraph_t g = nullptr;
+    HIP_TRY(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+    body();
+    const hipError_t ee = hipStreamEndCapture(e.stream, &g);
+    if (ee != hipSuccess || !g) {
+        set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+        return VMM_BA_ERR_HIP;
+    }
+    const hipError_t ei = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) {
+        *out = nullptr;
+        set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+        return VMM_BA_ERR_HIP;
+    }
+    return VMM_BA_OK;
+}
+
+static void drop_graphs(Engine& e)
+{
+    for (auto& g : e.iter_graph_seg)
+        if (g) {
+            (void)hipGraphExecDestroy(g);
+            g = nullptr;
+        }
+    if (e.iter_graph) {
+        (void)hipGraphExecDestroy(e.iter_graph);
+        e.iter_graph = nullptr;
+    }
+}
+
+// The iteration is captured once into hipGraphs and replayed (about 35 small launches; eager enqueueing is
+// host-bound).  One GPU: one graph.  World > 1: the all-reduce callbacks are host calls, so the five kernel
+// groups between them are five graphs launched around the callbacks.
 static int run_iteration(Engine& e, const vmm_ba_options& o)
 {
-    if (e.multi || !e.use_graph)
+    if (!e.use_graph)
         return enqueue_iteration(e, o);
     if (!e.launched_eagerly) {
         // the first iteration of a handle runs eagerly: first launches may load code objects or size
@@ -295,32 +359,34 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
         e.launched_eagerly = true;
         return enqueue_iteration(e, o);
     }
-    if (!e.iter_graph || e.graph_robustify != o.robustify || e.graph_huber_a != o.huber_a) {
-        if (e.iter_graph) {
-            (void)hipGraphExecDestroy(e.iter_graph);
-            e.iter_graph = nullptr;
-        }
-        hipGraph_t g = nullptr;
-        HIP_TRY(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_iteration(e, o);
-        const hipError_t ee = hipStreamEndCapture(e.stream, &g);
-        if (rc)
+    const bool have = e.multi ? e.iter_graph_seg[0] != nullptr : e.iter_graph != nullptr;
+    if (!have || e.graph_robustify != o.robustify || e.graph_huber_a != o.huber_a) {
+        drop_graphs(e);
+        int rc;
+        if (e.multi) {
+            for (int seg = 0; seg < 5; ++seg)
+                if ((rc = capture_graph(e, &e.iter_graph_seg[seg], [&] { enqueue_segment(e, o, seg); }))) {
+                    drop_graphs(e);
+                    return rc;
+                }
+        } else if ((rc = capture_graph(e, &e.iter_graph, [&] {
+                       for (int seg = 0; seg < 5; ++seg)
+                           enqueue_segment(e, o, seg);
+                   })))
             return rc;
-        if (ee != hipSuccess || !g) {
-            set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
-            return VMM_BA_ERR_HIP;
-        }
-        const hipError_t ei = hipGraphInstantiate(&e.iter_graph, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (ei != hipSuccess) {
-            e.iter_graph = nullptr;
-            set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
-            return VMM_BA_ERR_HIP;
-        }
         e.graph_robustify = o.robustify;
         e.graph_huber_a = o.huber_a;
     }
-    HIP_TRY(hipGraphLaunch(e.iter_graph, e.stream));
+    if (!e.multi) {
+        HIP_TRY(hipGraphLaunch(e.iter_graph, e.stream));
+        return VMM_BA_OK;
+    }
+    int rc;
+    for (int seg = 0; seg < 5; ++seg) {
+        HIP_TRY(hipGraphLaunch(e.iter_graph_seg[seg], e.stream));
+        if ((rc = allreduce_after(e, seg)))
+            return rc;
+    }
     return VMM_BA_OK;
 }
 
@@ -656,10 +722,7 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
         int rc;
         if ((rc = dev_alloc(e, &e.trace, (size_t)need_cap, false))) return rc;
         e.trace_capacity = need_cap;
-        if (e.iter_graph) {   // the captured k_lm_begin holds the old trace pointer
-            (void)hipGraphExecDestroy(e.iter_graph);
-            e.iter_graph = nullptr;
-        }
+        drop_graphs(e);   // the captured k_iter_begin holds the old trace pointer
     }
     init_ctl(*e.ctl_host, o, user_cap);
     HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
@@ -1105,10 +1168,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     if (e.trace_capacity < 1) {
         if ((rc = dev_alloc(e, &e.trace, 1, false))) return rc;
         e.trace_capacity = 1;
-        if (e.iter_graph) {
-            (void)hipGraphExecDestroy(e.iter_graph);
-            e.iter_graph = nullptr;
-        }
+        drop_graphs(e);
     }
     vmm_ba_options ot = o;
     ot.max_num_iterations = 1 << 30;
