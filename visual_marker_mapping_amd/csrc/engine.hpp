@@ -121,6 +121,7 @@ struct Engine {
     int n_red = 0, n_pad = 0, ldz = 0, n_blk = 0;   // reduced order, padded, leading dim, blocks
     SyrkPlan syrk;                  // stream-K plan of S = Z^T Z
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
+    double* S_packed = nullptr;     // world > 1: rows 0..n_pad of the lower triangle, packed, for the all-reduce
     double* P = nullptr;            // [2][kNB][ldz] transposed Cholesky panels (alternating)
     double* P2[2] = { nullptr, nullptr };
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
@@ -170,6 +171,7 @@ void launch_elim(Engine& e);
 void launch_syrk_only(Engine& e);
 void launch_syrk_reduced(Engine& e);
 void launch_add_diag(Engine& e);
+void launch_pack_lower(Engine& e, bool unpack);
 void launch_syrk_plan(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, const SyrkPlan& p);
 void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int ld, int n_rows, double* S);
 // kernels_chol.hip

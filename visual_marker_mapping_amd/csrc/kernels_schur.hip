@@ -434,6 +434,33 @@ void launch_syrk_reduced(Engine& e)
                        plan_dev(e.syrk), e.ldz, e.n_pad + 1, e.S, da);
 }
 
+// World > 1: only the lower triangle of the reduced system (rows 0..n_pad, row r holds r+1 entries, the rhs row
+// n_pad holds n_pad+1) travels through the all-reduce: (n_pad+1)(n_pad+2)/2 doubles instead of (n_pad+1) * ld.
+__global__ __launch_bounds__(256) void k_pack_lower(const LmCtl* ctl, const double* __restrict__ S, int ld, int n_rows,
+                                                    double* __restrict__ packed, bool unpack, double* __restrict__ Sout)
+{
+    if (ctl && ctl->done)
+        return;
+    const int r = blockIdx.x;
+    if (r >= n_rows)
+        return;
+    const int64_t base = (int64_t)r * (r + 1) / 2;
+    for (int c = threadIdx.x; c <= r; c += 256) {
+        if (unpack)
+            Sout[(int64_t)r * ld + c] = packed[base + c];
+        else
+            packed[base + c] = S[(int64_t)r * ld + c];
+    }
+}
+
+void launch_pack_lower(Engine& e, bool unpack)
+{
+    if (!e.multi)
+        return;
+    hipLaunchKernelGGL(k_pack_lower, dim3(e.n_pad + 1), dim3(256), 0, e.stream, (const LmCtl*)e.ctl, (const double*)e.S,
+                       e.ldz, e.n_pad + 1, e.S_packed, unpack, e.S);
+}
+
 void launch_add_diag(Engine& e)
 {
     if (!e.multi)

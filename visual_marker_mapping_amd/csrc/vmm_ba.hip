@@ -267,8 +267,10 @@ static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg)
         launch_iter_begin(e, e.multi ? e.small_stage : e.small);
         launch_elim(e);
         launch_syrk_reduced(e);
+        launch_pack_lower(e, false);
         break;
     case 2:
+        launch_pack_lower(e, true);
         launch_add_diag(e);
         launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
         launch_backsub(e);
@@ -293,7 +295,7 @@ static int allreduce_after(Engine& e, int seg)
 {
     switch (seg) {
     case 0: return do_allreduce(e, e.small_stage, e.small_count);
-    case 1: return do_allreduce(e, e.S, (size_t)(e.n_pad + 1) * e.ldz);
+    case 1: return do_allreduce(e, e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2);
     case 2: return do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1);
     case 3: return do_allreduce(e, e.cost_comm, 1);
     default: return VMM_BA_OK;
@@ -615,6 +617,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     // 128-row blocks covering rows 0..n_pad (the last one holds the rhs row) and columns 0..n_pad-1
     if ((rc = make_syrk_plan(e, e.syrk, (e.n_pad + kST) / kST, (e.n_pad + kST - 1) / kST, e.k_pad))) return fail(rc);
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
+    if (e.multi && (rc = dev_alloc(e, &e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2))) return fail(rc);
     if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * e.ldz))) return fail(rc);
     if ((rc = setup_lookahead(e, e.n_blk, e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
