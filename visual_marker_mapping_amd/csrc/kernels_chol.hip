@@ -885,8 +885,9 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
                         hipGetErrorString(le));
         }
     }
-    // one chained launch while every workgroup of the chain can be resident; the per-block kernels otherwise
-    if (n_blk <= 200 && e.flags && e.gran && !e.no_chain) {
+    // one chained launch while every workgroup of the chain is certainly resident (one per CU); the per-block
+    // kernels otherwise
+    if (n_blk <= e.n_cu && e.flags && e.gran && !e.no_chain) {
         hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
                            e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
     } else {
