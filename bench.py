@@ -218,11 +218,22 @@ def main():
                                                     linear_solver=O.SCHUR_AUTO))
             dt = time.perf_counter() - t0
             cpu_iters = summ["num_cost_evals"]   # one cost evaluation per LM iteration
+            # the same oracle on ONE thread, bounded to two LM iterations (single-threaded and
+            # all-cores timings)
+            sc1 = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                          s.obs_px)
+            t0 = time.perf_counter()
+            summ1, _ = O.solve(sc1, O.default_options(robustify=robust, num_threads=1, max_num_iterations=2,
+                                                      linear_solver=O.SCHUR_AUTO))
+            dt1 = time.perf_counter() - t0
             line["cpu_baseline"] = {"value": cpu_iters / dt, "unit": "LM iterations/s", "cores": threads,
                                     "kind": "port",
                                     "sample": "one complete solve of the same workload (%d LM iterations, %.2f s) "
                                               "by oracle/liboracle.so (C + OpenMP, Schur elimination of the same "
-                                              "family); Ceres itself is not installable here" % (cpu_iters, dt)}
+                                              "family); Ceres itself is not installable here" % (cpu_iters, dt),
+                                    "single_thread_value": max(summ1["num_cost_evals"], 1) / dt1,
+                                    "single_thread_sample": "%d LM iterations, %.2f s on one thread"
+                                                            % (summ1["num_cost_evals"], dt1)}
     ba.close()
     if use_dist:
         dist.barrier()
