@@ -77,8 +77,8 @@ static void quat_rotate(const double q[4], const double pt[3], double out[3])
     unit_quat_rotate(u, pt, out);
 }
 
-/* The part of the functor after the two rigid transforms: TagReconstructionCostFunction.h:125-152,
- * identical in arithmetic to CameraModel::projectPoint (CameraModel.cpp:6-26). */
+/* The part of the functor after the two rigid transforms: TagReconstructionCostFunction.h:125-152.
+ * NOT the arithmetic of CameraModel::projectPoint (see project_camera_model below). */
 static void project_distort(const double intr[4], const double dist[5], const double pc[3],
                             double uv[2])
 {
@@ -94,9 +94,27 @@ static void project_distort(const double intr[4], const double dist[5], const do
     uv[1] = intr[1] * yd + intr[3];
 }
 
+/* CameraModel::projectPoint, CameraModel.cpp:6-26, statement by statement.  pt is a Vector3d divided by its
+ * z (:9); r2 from the undistorted x, y (:18); pt.x() is OVERWRITTEN with the distorted value (:20-21) before
+ * pt.y() is computed (:22-23), so 2*p2*pt.x()*pt.y() uses the distorted x there (r2 and the remaining pt.y()
+ * factors are still undistorted); then (getK() * pt).head(2) (:25) = (fx*x + 0*y + cx*1, 0*x + fy*y + cy*1). */
+static void project_camera_model(const double intr[4], const double dist[5], const double pc[3],
+                                 double uv[2])
+{
+    double px = pc[0] / pc[2];
+    double py = pc[1] / pc[2];
+    const double pz = pc[2] / pc[2];
+    const double k1 = dist[0], k2 = dist[1], k3 = dist[4], p1 = dist[2], p2 = dist[3];
+    const double r2 = px * px + py * py;
+    px = px * (1 + r2 * (k1 + r2 * (k2 + r2 * k3))) + 2 * p1 * px * py + p2 * (r2 + 2 * px * px);
+    py = py * (1 + r2 * (k1 + r2 * (k2 + r2 * k3))) + 2 * p2 * px * py + p1 * (r2 + 2 * py * py);
+    uv[0] = (intr[0] * px + 0.0 * py) + intr[2] * pz;
+    uv[1] = (0.0 * px + intr[1] * py) + intr[3] * pz;
+}
+
 void vo_project_point(const double intr[4], const double dist[5], const double pc[3], double uv[2])
 {
-    project_distort(intr, dist, pc, uv);
+    project_camera_model(intr, dist, pc, uv);
 }
 
 void vo_corner_residual(const double intr[4], const double dist[5], const double cam_qt[7],
@@ -1094,7 +1112,7 @@ void vo_reprojection_stats(const vo_problem* p, double* per_cam_mean, double* pe
                 pw[a] = (Rt[3 * a] * cl[0] + Rt[3 * a + 1] * cl[1] + Rt[3 * a + 2] * cl[2]) + tq[4 + a];
             for (int a = 0; a < 3; ++a)  /* TagReconstructor.cpp:362 */
                 pc[a] = (Rc[3 * a] * pw[0] + Rc[3 * a + 1] * pw[1] + Rc[3 * a + 2] * pw[2]) + cq[4 + a];
-            project_distort(p->intr, p->dist, pc, uv);
+            project_camera_model(p->intr, p->dist, pc, uv);   /* :362: camModel.projectPoint */
             const double du = uv[0] - p->obs_px[8 * i + 2 * k];
             const double dv = uv[1] - p->obs_px[8 * i + 2 * k + 1];
             if (per_corner) {

@@ -63,6 +63,39 @@ def corner_residual(intr, dist, cam, tag, cl, uv):
     return [intr[0] * xd + intr[2] - uv[0], intr[1] * yd + intr[3] - uv[1]]
 
 
+def project_camera_model(intr, dist, pc):
+    """CameraModel::projectPoint, /root/reference/src/CameraModel.cpp:6-26, statement by statement: pt.x() is
+    overwritten at :20-21 BEFORE :22-23 evaluates 2*p2*pt.x()*pt.y(), so the y term sees the DISTORTED x
+    (r2 and pt.y() are still the undistorted values).  Not the functor's formula (CostFunction.h:141-144)."""
+    x, y = pc[0] / pc[2], pc[1] / pc[2]
+    k1, k2, p1, p2, k3 = dist
+    r2 = x * x + y * y
+    xd = x * (1 + r2 * (k1 + r2 * (k2 + r2 * k3))) + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * (1 + r2 * (k1 + r2 * (k2 + r2 * k3))) + 2 * p2 * xd * y + p1 * (r2 + 2 * y * y)
+    return [intr[0] * xd + intr[2], intr[1] * yd + intr[3]]
+
+
+def eigen_rotate(q, p):
+    """Eigen::Quaterniond::toRotationMatrix() * p -- no normalisation (TagReconstructor.h:37,
+    src/TagReconstructor.cpp:356)."""
+    w, x, y, z = q
+    R = [[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]]
+    return [sum(R[i][k] * p[k] for k in range(3)) for i in range(3)]
+
+
+def corner_reprojection_error(intr, dist, cam, tag, cl, uv):
+    """One term of computeReprojectionErrorPer{Img,Tag,Corner} (src/TagReconstructor.cpp:353-363):
+    camModel.projectPoint(R_c * (R_t * corner + t_t) + t_c) - observed corner."""
+    pw = eigen_rotate(tag[:4], cl)
+    pw = [pw[i] + tag[4 + i] for i in range(3)]
+    pc = eigen_rotate(cam[:4], pw)
+    pc = [pc[i] + cam[4 + i] for i in range(3)]
+    uvp = project_camera_model(intr, dist, pc)
+    return [uvp[0] - uv[0], uvp[1] - uv[1]]
+
+
 def local_corners(w, h):
     return [[-w / 2, -h / 2, mpf(0)], [w / 2, -h / 2, mpf(0)], [w / 2, h / 2, mpf(0)],
             [-w / 2, h / 2, mpf(0)]]
@@ -131,9 +164,14 @@ def main():
                     rowt.append(diff(ft, mpf(0)))
                 Jc.append(rowc)
                 Jt.append(rowt)
+        # the same observation through the STATISTICS path (CameraModel::projectPoint + Eigen rotations)
+        rep = []
+        for k, cl in enumerate(cls):
+            rep += corner_reprojection_error(intrm, distm, camm, tagm, cl, pxm[2 * k:2 * k + 2])
         cases.append({
             "intr": intr, "dist": dist, "cam_qt": cam, "tag_qt": tag, "wh": [w, h], "px": px,
             "residual": [float(v) for v in res],
+            "reprojection_error_camera_model": [float(v) for v in rep],
             "J_cam": [[float(v) for v in row] for row in Jc],
             "J_tag": [[float(v) for v in row] for row in Jt],
         })
@@ -158,8 +196,29 @@ def main():
         else:
             rho = [sm, mpf(1), mpf(0)]
         huber.append({"a": 1.0, "s": s, "rho": [float(v) for v in rho]})
+    # CameraModel::projectPoint known answers (aliased y term), README distortion and none, normalised image
+    # coordinates out to |x|, |y| ~ 0.4 (the image corners of the README camera are at 0.37 / 0.25)
+    rng2 = random.Random(20261005)
+    project = []
+    fixed = [(0.3, 0.2), (0.35, -0.24), (-0.37, 0.24), (0.0, 0.0), (0.4, 0.4), (-0.4, -0.4)]
+    for pi in range(24):
+        dist = dist_readme if pi % 4 else [0.0] * 5
+        if pi < len(fixed):
+            xn, yn = fixed[pi]
+            dist = dist_readme
+        else:
+            xn, yn = rng2.uniform(-0.4, 0.4), rng2.uniform(-0.4, 0.4)
+        Z = rng2.uniform(0.5, 6.0)
+        pc = [xn * Z, yn * Z, Z]
+        uv = project_camera_model([mpf(c) for c in intr], [mpf(c) for c in dist], [mpf(c) for c in pc])
+        fun = corner_residual([mpf(c) for c in intr], [mpf(c) for c in dist],
+                              [mpf(1), mpf(0), mpf(0), mpf(0), mpf(0), mpf(0), mpf(0)],
+                              [mpf(1), mpf(0), mpf(0), mpf(0)] + [mpf(c) for c in pc],
+                              [mpf(0), mpf(0), mpf(0)], [mpf(0), mpf(0)])
+        project.append({"intr": intr, "dist": dist, "point_cam": pc, "uv": [float(v) for v in uv],
+                        "uv_functor_formula": [float(v) for v in fun]})
     out = {"generator": "tests/golden/make_kats.py (mpmath %d digits)" % mp.dps,
-           "obs": cases, "plus": plus_cases, "huber": huber}
+           "obs": cases, "plus": plus_cases, "huber": huber, "project_point": project}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_residual.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

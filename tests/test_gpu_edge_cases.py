@@ -135,3 +135,39 @@ def test_observation_mask_equals_a_rebuilt_subproblem(oracle):
     finally:
         full.close()
         sub.close()
+
+
+def test_masked_observation_on_the_camera_plane_does_not_poison_the_solve(oracle):
+    """A switched-off observation whose parked poses put the tag centre exactly on the camera plane (Z_c == 0:
+    identity camera at the origin, tag at z = 0) would give 1/Z = inf; it must be selected out, not multiplied
+    by zero (0 * inf = NaN in the cost, g, H, W).  The solve must equal the one without that observation."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=6, n_tags=5)
+    cam0 = np.vstack([s.cam_init, [[1.0, 0, 0, 0, 0, 0, 0]]])          # parked camera: identity at the origin
+    tag0 = np.vstack([s.tag_init, [[1.0, 0, 0, 0, 0.3, -0.2, 0.0]]])   # parked tag on that camera's plane z = 0
+    wh = np.vstack([s.tag_wh, s.tag_wh[:1]])
+    oc = np.concatenate([s.obs_cam, [6, 6, 0]]).astype(np.int32)
+    ot = np.concatenate([s.obs_tag, [5, 0, 5]]).astype(np.int32)
+    px = np.vstack([s.obs_px, np.full((3, 8), 100.0)])
+    mask = np.ones(len(oc), np.uint8)
+    mask[-3:] = 0
+    ba = eng.BundleAdjuster(s.intr, s.dist, cam0, tag0, wh, 0, oc, ot, px)
+    ref = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px)
+    try:
+        ba.set_observation_mask(mask)
+        assert np.isfinite(ba.cost(robustify=True))
+        blocks = ba.eval_blocks(robustify=True)
+        assert all(np.all(np.isfinite(blocks[k])) for k in ("V", "U", "W", "g_cam", "g_tag"))
+        assert np.all(blocks["W"][-3:] == 0.0)
+        o = eng.default_options(robustify=1)
+        a, b = ba.solve(o, trace_capacity=64), ref.solve(o, trace_capacity=64)
+        assert a["termination_type"] == b["termination_type"] == eng.CONVERGENCE
+        assert a["iterations"] == b["iterations"] and a["final_cost"] == pytest.approx(b["final_cost"], rel=1e-12)
+        (ca, ta), (cb, tb) = ba.get_state(), ref.get_state()
+        np.testing.assert_allclose(ca[:6], cb, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(ta[:5], tb, rtol=0, atol=1e-10)
+        assert np.array_equal(ca[6], cam0[6]) and np.array_equal(ta[5], tag0[5])
+    finally:
+        ba.close()
+        ref.close()

@@ -86,9 +86,28 @@ def test_reprojection_statistics_and_pruning(oracle, capsys):
 
 
 def test_project_point_is_camera_model_project_point(oracle, kats):
+    # through vmm_ba_project_points; CameraModel.cpp:20-23 (aliased y term) pinned by the mpmath KATs at 1e-9 px
     from visual_marker_mapping_amd import tag_reconstructor as tr
-    case = kats["obs"][1]
-    cm = tr.CameraModel(*case["intr"], case["dist"])
-    p = np.array([0.3, -0.2, 2.5])
-    np.testing.assert_allclose(cm.projectPoint(p), oracle.project_point(case["intr"], case["dist"], p), atol=1e-9)
-    assert cm.projectPoint(np.tile(p, (5, 1))).shape == (5, 2)
+    from visual_marker_mapping_amd import engine as eng
+    for case in kats["project_point"]:
+        cm = tr.CameraModel(*case["intr"], case["dist"])
+        np.testing.assert_allclose(cm.projectPoint(np.array(case["point_cam"])), case["uv"], rtol=0, atol=1e-9)
+    c0 = kats["project_point"][0]
+    pts = np.array([c["point_cam"] for c in kats["project_point"] if c["dist"] == c0["dist"]])
+    ref = np.array([c["uv"] for c in kats["project_point"] if c["dist"] == c0["dist"]])
+    np.testing.assert_allclose(eng.project_points(c0["intr"], c0["dist"], pts), ref, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(eng.project_points(c0["intr"], c0["dist"], pts[0]),
+                               [oracle.project_point(c0["intr"], c0["dist"], pts[0])], rtol=0, atol=1e-9)
+
+
+def test_reprojection_stats_match_camera_model_kats(kats):
+    # through vmm_ba_reprojection_stats: src/TagReconstructor.cpp:353-363 = Eigen rotations + projectPoint
+    from visual_marker_mapping_amd import engine as eng
+    for case in kats["obs"]:
+        with eng.BundleAdjuster(case["intr"], case["dist"], [case["cam_qt"]], [case["tag_qt"]], [case["wh"]], -1,
+                                [0], [0], [case["px"]]) as ba:
+            pc, pt, avg, corner = ba.reprojection_stats()
+        ref = np.array(case["reprojection_error_camera_model"])
+        np.testing.assert_allclose(corner[0], ref, rtol=0, atol=2e-9)
+        mean = np.sqrt((ref.reshape(4, 2) ** 2).sum(axis=1)).sum() / 4
+        np.testing.assert_allclose([pc[0], pt[0], avg], mean, rtol=1e-12)

@@ -35,15 +35,25 @@ def test_huber_matches_closed_form(oracle, kats):
                                    atol=0)
 
 
-def test_project_point_is_the_functor_tail(oracle, kats):
-    # CameraModel::projectPoint (CameraModel.cpp:6-26) == CostFunction.h:125-152
-    case = kats["obs"][1]
-    uv = oracle.project_point(case["intr"], case["dist"], [0.3, -0.2, 2.5])
-    x, y = 0.3 / 2.5, -0.2 / 2.5
-    r2 = x * x + y * y
-    k1, k2, p1, p2, k3 = case["dist"]
-    rad = 1 + r2 * (k1 + r2 * (k2 + r2 * k3))
-    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
-    yd = y * rad + 2 * p2 * x * y + p1 * (r2 + 2 * y * y)
-    np.testing.assert_allclose(uv, [case["intr"][0] * xd + case["intr"][2],
-                                    case["intr"][1] * yd + case["intr"][3]], rtol=1e-14)
+def test_project_point_matches_camera_model_kats(oracle, kats):
+    # CameraModel::projectPoint (CameraModel.cpp:6-26): pt.x() is overwritten before pt.y() is computed, so the
+    # y tangential term sees the distorted x -- NOT the functor's formula (CostFunction.h:141-144).
+    worst = 0.0
+    for case in kats["project_point"]:
+        uv = oracle.project_point(case["intr"], case["dist"], case["point_cam"])
+        np.testing.assert_allclose(uv, case["uv"], rtol=0, atol=1e-9)
+        worst = max(worst, abs(case["uv"][1] - case["uv_functor_formula"][1]))
+    assert worst > 0.01   # the two formulas really differ at README distortion (up to 0.02 px)
+
+
+def test_reprojection_statistics_match_camera_model_kats(oracle, kats):
+    # computeReprojectionErrorPerCorner (src/TagReconstructor.cpp:430-455): Eigen rotations (no normalisation)
+    # + CameraModel::projectPoint, one observation per KAT case
+    for case in kats["obs"]:
+        sc = oracle.Scene(case["intr"], case["dist"], [case["cam_qt"]], [case["tag_qt"]], [case["wh"]], -1,
+                          [0], [0], [case["px"]])
+        pc, pt, avg, corner = oracle.reprojection_stats(sc)
+        ref = np.array(case["reprojection_error_camera_model"])
+        np.testing.assert_allclose(corner[0], ref, rtol=0, atol=2e-9)
+        mean = np.sqrt((ref.reshape(4, 2) ** 2).sum(axis=1)).sum() / 4
+        np.testing.assert_allclose([pc[0], pt[0], avg], mean, rtol=1e-12)

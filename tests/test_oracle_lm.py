@@ -88,7 +88,9 @@ def test_robust_cost_is_per_corner_huber(oracle):
     # Huber acts on the squared norm of the 2-vector corner residual (TagReconstructor.cpp:721)
     s = make_scene(5, n_cams=6, n_tags=4)
     sc = _scene(oracle, s, init=False)
-    _, _, _, per_corner = oracle.reprojection_stats(sc)
+    # the functor's residuals (the statistics use CameraModel::projectPoint, a different formula with distortion)
+    per_corner = np.array([oracle.obs_eval(sc.intr, sc.dist, sc.cam_qt[c], sc.tag_qt[t], sc.tag_wh[t], px, jac=False)
+                           for c, t, px in zip(sc.obs_cam, sc.obs_tag, sc.obs_px)])
     sq = (per_corner.reshape(-1, 4, 2) ** 2).sum(axis=2)
     rho = np.where(sq > 1.0, 2.0 * np.sqrt(sq) - 1.0, sq)
     np.testing.assert_allclose(oracle.cost(sc, oracle.default_options(robustify=1)),

@@ -138,6 +138,12 @@ struct Engine {
     double* part_k1 = nullptr;      // [ordE.n_tasks] candidate-cost wave partials
     double* pose_part = nullptr;    // [n_pose][5] per-pose terms of the step decision
 
+    // reprojection statistics (vmm_ba_reprojection_stats): per-task partials, per-pose sums | counts
+    double* stats_part = nullptr;   // [n_tasks by camera + n_tasks by tag]
+    int32_t* stats_cnt = nullptr;   // same layout: active observations per task
+    double* stats_pose = nullptr;   // [2 * (n_cams + n_tags)]
+    double* stats_corner = nullptr; // [8 * n_obs], allocated by the first call that asks for per-corner errors
+
     LmCtl* ctl = nullptr;           // device
     LmCtl* ctl_host = nullptr;      // pinned
     vmm_ba_iteration* trace = nullptr;  // device
@@ -163,7 +169,7 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
 void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a);
 void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a,
                  double* out_scalar);
-void launch_stats(Engine& e, double* part_cam, double* part_tag, int32_t* n_cam, int32_t* n_tag, double* per_corner_dev);
+void launch_stats(Engine& e, double* per_corner_dev);
 void launch_project(hipStream_t st, const Intrinsics& K, int64_t n, const double* pc, double* uv);
 void launch_sum(Engine& e, bool guard, const double* in, int n, double* out);
 // kernels_schur.hip

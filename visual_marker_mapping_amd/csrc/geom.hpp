@@ -58,11 +58,25 @@ struct CornerEval {
     double jt[2][6];
 };
 
+// The tangential y term of the two projections the reference holds:
+//   functor      (CostFunction.h:143-144)  yd = y rad + 2 p2 x  y + p1 (r2 + 2 y^2)
+//   CameraModel  (src/CameraModel.cpp:20-23) pt.x() has already been overwritten with the distorted xd when
+//                pt.y() is computed:        yd = y rad + 2 p2 xd y + p1 (r2 + 2 y^2)
+// The cost/Jacobian path is the functor; the statistics and projectPoint are CameraModel (they differ by up to
+// 0.02 px with the README distortion).
+__device__ __forceinline__ void distort(const Intrinsics& K, bool camera_model, double x, double y, double r2,
+                                        double rad, double& xd, double& yd)
+{
+    xd = x * rad + 2.0 * K.p1 * x * y + K.p2 * (r2 + 2.0 * x * x);
+    yd = y * rad + 2.0 * K.p2 * (camera_model ? xd : x) * y + K.p1 * (r2 + 2.0 * y * y);
+}
+
 // sx, sy in {-1,+1}: which corner of the quad; hw, hh: half width / half height of the tag.
-template <bool NEED_JC, bool NEED_JT>
+// CAMERA_MODEL: project like CameraModel::projectPoint (statistics path; no Jacobians exist for it).
+template <bool NEED_JC, bool NEED_JT, bool CAMERA_MODEL = false>
 __device__ __forceinline__ void eval_corner(const Intrinsics& K, const Rigid& cam, const Rigid& tag,
                                             double sxhw, double syhh, double u_obs, double v_obs,
-                                            CornerEval& e)
+                                            CornerEval& e, const bool on = true)
 {
     // a = R_t p_l (p_l.z == 0), P_w = a + t_t                        CostFunction.h:107-114
     const double a0 = tag.R[0] * sxhw + tag.R[1] * syhh;
@@ -74,12 +88,16 @@ __device__ __forceinline__ void eval_corner(const Intrinsics& K, const Rigid& ca
     const double b1 = cam.R[3] * w0 + cam.R[4] * w1 + cam.R[5] * w2;
     const double b2 = cam.R[6] * w0 + cam.R[7] * w1 + cam.R[8] * w2;
     const double X = b0 + cam.t[0], Y = b1 + cam.t[1], Z = b2 + cam.t[2];
-    const double iz = 1.0 / Z;
+    // a switched-off observation (on == false; weighted zero by the caller) is evaluated at the principal
+    // point instead: its poses are parked defaults and may put the corner on the camera plane (Z == 0), and
+    // 0 * inf would poison the sums
+    const double iz = on ? 1.0 / Z : 0.0;
     const double x = X * iz, y = Y * iz;             // :125-126
     const double r2 = x * x + y * y;                 // :129
     const double rad = 1.0 + r2 * (K.k1 + r2 * (K.k2 + r2 * K.k3));
-    const double xd = x * rad + 2.0 * K.p1 * x * y + K.p2 * (r2 + 2.0 * x * x);   // :141-142
-    const double yd = y * rad + 2.0 * K.p2 * x * y + K.p1 * (r2 + 2.0 * y * y);   // :143-144
+    static_assert(!(CAMERA_MODEL && (NEED_JC || NEED_JT)), "the CameraModel projection is residual-only");
+    double xd, yd;
+    distort(K, CAMERA_MODEL, x, y, r2, rad, xd, yd);   // :141-144 / CameraModel.cpp:20-23
     e.ru = K.fx * xd + K.cx - u_obs;                 // :151-156
     e.rv = K.fy * yd + K.cy - v_obs;
     if (!NEED_JC && !NEED_JT)

@@ -62,8 +62,8 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
     const double hw = 0.5 * a.tag_wh[2 * tag_idx], hh = 0.5 * a.tag_wh[2 * tag_idx + 1];
     // a constant (origin) tag contributes no Jacobian columns (src/TagReconstructor.cpp:669-673)
     const double tag_on = (tag_idx == a.fixed_tag) ? 0.0 : 1.0;
-    // switched-off observations are evaluated like the others (their poses must be finite) and weighted 0
-    const double mask = (valid && a.mask[a.caller[is]]) ? 1.0 : 0.0;
+    // switched-off observations are selected out, never multiplied out (their poses are parked defaults)
+    const bool on = valid && a.mask[a.caller[is]];
 
     AT H[21];
     double g[6], cost = 0.0;
@@ -90,12 +90,12 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
         const double u = a.px[(2 * c) * a.n_pad + is];
         const double v = a.px[(2 * c + 1) * a.n_pad + is];
         CornerEval e;
-        eval_corner<NEED_JC, NEED_JT>(a.K, cam, tag, sx, sy, u, v, e);
+        eval_corner<NEED_JC, NEED_JT>(a.K, cam, tag, sx, sy, u, v, e, on);
         const double s = e.ru * e.ru + e.rv * e.rv;
         double rho0, wgt;
         huber(a.robustify != 0, a.huber_a, s, rho0, wgt);
-        wgt *= mask;
-        cost += 0.5 * rho0 * mask;
+        wgt = on ? wgt : 0.0;
+        cost += on ? 0.5 * rho0 : 0.0;
         const double w_own = OWN_IS_CAM ? wgt : wgt * tag_on;
         const double w_oth = OWN_IS_CAM ? wgt * tag_on : wgt;
 #pragma unroll
@@ -360,8 +360,9 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a)
         const double sx = (c == 1 || c == 2) ? hw : -hw;
         const double sy = (c >= 2) ? hh : -hh;
         CornerEval e;
-        eval_corner<false, false>(a.K, cam, tag, sx, sy, a.px[(2 * c) * a.n_pad + is],
-                                  a.px[(2 * c + 1) * a.n_pad + is], e);
+        // camModel.projectPoint(R * pts3d[i] + t) - tagObs.corners[i]   (src/TagReconstructor.cpp:361-362)
+        eval_corner<false, false, true>(a.K, cam, tag, sx, sy, a.px[(2 * c) * a.n_pad + is],
+                                        a.px[(2 * c + 1) * a.n_pad + is], e);
         sum += sqrt(e.ru * e.ru + e.rv * e.rv);
         if (a.per_corner && valid) {
             a.per_corner[8 * ci + 2 * c] = on ? e.ru : 0.0;
@@ -376,6 +377,31 @@ __global__ __launch_bounds__(256) void k_stats(const StatsArgs a)
     }
 }
 
+// Per pose: the sum of its tasks' partial sums (task order) and the number of corner blocks behind it
+// (4 per active observation): the numerators and denominators of src/TagReconstructor.cpp:366-373,412-422.
+__global__ void k_stats_pose(int n_cam, const int32_t* __restrict__ task_c, const double* __restrict__ part_c,
+                             const int32_t* __restrict__ cnt_c, int n_tag, const int32_t* __restrict__ task_t,
+                             const double* __restrict__ part_t, const int32_t* __restrict__ cnt_t,
+                             double* __restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_cam + n_tag)
+        return;
+    const bool is_cam = p < n_cam;
+    const int q = is_cam ? p : p - n_cam;
+    const int32_t* pt = is_cam ? task_c : task_t;
+    const double* part = is_cam ? part_c : part_t;
+    const int32_t* cnt = is_cam ? cnt_c : cnt_t;
+    double s = 0.0;
+    int64_t n = 0;
+    for (int t = pt[q]; t < pt[q + 1]; ++t) {
+        s += part[t];
+        n += 4 * (int64_t)cnt[t];
+    }
+    out[p] = s;
+    out[n_cam + n_tag + p] = (double)n;
+}
+
 // CameraModel::projectPoint (src/CameraModel.cpp:6-26) for a batch of camera-frame points.
 __global__ void k_project(Intrinsics K, int64_t n, const double* __restrict__ pc, double* __restrict__ uv)
 {
@@ -386,8 +412,8 @@ __global__ void k_project(Intrinsics K, int64_t n, const double* __restrict__ pc
     const double x = X / Z, y = Y / Z;
     const double r2 = x * x + y * y;
     const double rad = 1.0 + r2 * (K.k1 + r2 * (K.k2 + r2 * K.k3));
-    const double xd = x * rad + 2.0 * K.p1 * x * y + K.p2 * (r2 + 2.0 * x * x);
-    const double yd = y * rad + 2.0 * K.p2 * x * y + K.p1 * (r2 + 2.0 * y * y);
+    double xd, yd;
+    distort(K, true, x, y, r2, rad, xd, yd);   // :20-23: the y term uses the already distorted x
     uv[2 * i] = K.fx * xd + K.cx;
     uv[2 * i + 1] = K.fy * yd + K.cy;
 }
@@ -540,10 +566,16 @@ void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, in
     launch_sum(e, guard, e.part_k1, e.ordE.n_tasks, out_scalar);
 }
 
-void launch_stats(Engine& e, double* part_cam, double* part_tag, int32_t* n_cam, int32_t* n_tag, double* per_corner_dev)
+// Both statistics passes + the per-pose sums: e.stats_pose = [sum per camera | sum per tag | count per camera |
+// count per tag] (counts as doubles).  All buffers belong to the handle.
+void launch_stats(Engine& e, double* per_corner_dev)
 {
     const ObsOrder& oc = e.elim_cams ? e.ordE : e.ordF;  // sorted by camera
     const ObsOrder& ot = e.elim_cams ? e.ordF : e.ordE;  // sorted by tag
+    double* part_cam = e.stats_part;
+    double* part_tag = e.stats_part + oc.n_tasks;
+    int32_t* n_cam = e.stats_cnt;
+    int32_t* n_tag = e.stats_cnt + oc.n_tasks;
     StatsArgs a;
     a.K = e.K;
     a.tag_wh = e.tag_wh;
@@ -558,6 +590,9 @@ void launch_stats(Engine& e, double* part_cam, double* part_tag, int32_t* n_cam,
     a.per_corner = nullptr;
     if (a.n_tasks > 0)
         hipLaunchKernelGGL((k_stats<false>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);
+    hipLaunchKernelGGL(k_stats_pose, dim3((e.n_cams + e.n_tags + 255) / 256), dim3(256), 0, e.stream, e.n_cams,
+                       (const int32_t*)oc.pose_task, (const double*)part_cam, (const int32_t*)n_cam, e.n_tags,
+                       (const int32_t*)ot.pose_task, (const double*)part_tag, (const int32_t*)n_tag, e.stats_pose);
 }
 
 void launch_project(hipStream_t st, const Intrinsics& K, int64_t n, const double* pc, double* uv)

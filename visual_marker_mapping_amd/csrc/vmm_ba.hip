@@ -591,7 +591,16 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.ev_g_tag = e.ev_g_cam + (size_t)6 * e.n_cams;
     e.ev_cost = e.ev_g_tag + (size_t)6 * e.n_tags;
     if ((rc = dev_alloc(e, &e.obs_mask, (size_t)std::max<int64_t>(e.n_obs, 1), false))) return fail(rc);
-    HIP_TRY(hipMemsetAsync(e.obs_mask, 1, (size_t)std::max<int64_t>(e.n_obs, 1), e.stream));
+    if (hipMemsetAsync(e.obs_mask, 1, (size_t)std::max<int64_t>(e.n_obs, 1), e.stream) != hipSuccess) {
+        set_error("hipMemsetAsync(obs_mask) failed");
+        return fail(VMM_BA_ERR_HIP);
+    }
+    {
+        const size_t n_stat = (size_t)e.ordE.n_tasks + (size_t)e.ordF.n_tasks + 1;
+        if ((rc = dev_alloc(e, &e.stats_part, n_stat))) return fail(rc);
+        if ((rc = dev_alloc(e, &e.stats_cnt, n_stat))) return fail(rc);
+        if ((rc = dev_alloc(e, &e.stats_pose, (size_t)2 * n_pose))) return fail(rc);
+    }
     if (e.f32_accum) {
         if ((rc = dev_alloc(e, &e.Wf, (size_t)36 * e.ordE.n_pad))) return fail(rc);
     } else if ((rc = dev_alloc(e, &e.W, (size_t)36 * e.ordE.n_pad))) return fail(rc);
@@ -723,9 +732,16 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
     const int need_cap = std::max(user_cap, 1);
     if (need_cap > e.trace_capacity) {
         int rc;
+        drop_graphs(e);   // the captured k_iter_begin holds the old trace pointer
+        if (e.trace) {
+            HIP_TRY(hipStreamSynchronize(e.stream));
+            e.allocs.erase(std::remove(e.allocs.begin(), e.allocs.end(), (void*)e.trace), e.allocs.end());
+            (void)hipFree(e.trace);
+            e.trace = nullptr;
+            e.trace_capacity = 0;
+        }
         if ((rc = dev_alloc(e, &e.trace, (size_t)need_cap, false))) return rc;
         e.trace_capacity = need_cap;
-        drop_graphs(e);   // the captured k_iter_begin holds the old trace pointer
     }
     init_ctl(*e.ctl_host, o, user_cap);
     HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
@@ -815,70 +831,38 @@ int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per
     }
     Engine& e = *reinterpret_cast<Engine*>(h);
     HIP_TRY(hipSetDevice(e.device));
-    const ObsOrder& oc = e.elim_cams ? e.ordE : e.ordF;
-    const ObsOrder& ot = e.elim_cams ? e.ordF : e.ordE;
-    double *d_pc = nullptr, *d_pt = nullptr, *d_corner = nullptr;
-    int32_t *d_nc = nullptr, *d_nt = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_pc, sizeof(double) * std::max(1, oc.n_tasks)));
-    HIP_TRY(hipMalloc((void**)&d_pt, sizeof(double) * std::max(1, ot.n_tasks)));
-    HIP_TRY(hipMalloc((void**)&d_nc, sizeof(int32_t) * std::max(1, oc.n_tasks)));
-    HIP_TRY(hipMalloc((void**)&d_nt, sizeof(int32_t) * std::max(1, ot.n_tasks)));
+    const int n_pose = e.n_cams + e.n_tags;
+    if (per_corner && e.n_obs > 0 && !e.stats_corner) {
+        int rc;
+        if ((rc = dev_alloc(e, &e.stats_corner, (size_t)8 * e.n_obs, false))) return rc;
+    }
+    launch_stats(e, (per_corner && e.n_obs > 0) ? e.stats_corner : nullptr);
+    HIP_TRY(hipGetLastError());
+    // per-pose sums and counts come back in one copy; the means and the average are formed here in the
+    // reference's order (per tag, ascending: src/TagReconstructor.cpp:416-426)
+    std::vector<double> pose((size_t)2 * n_pose);
+    HIP_TRY(hipMemcpyAsync(pose.data(), e.stats_pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost, e.stream));
     if (per_corner && e.n_obs > 0)
-        HIP_TRY(hipMalloc((void**)&d_corner, sizeof(double) * 8 * e.n_obs));
-    launch_stats(e, d_pc, d_pt, d_nc, d_nt, d_corner);
-    std::vector<double> pc((size_t)oc.n_tasks), pt((size_t)ot.n_tasks);
-    std::vector<int32_t> cnc((size_t)oc.n_tasks), cnt((size_t)ot.n_tasks);
-    std::vector<Task> tc((size_t)oc.n_tasks), tt((size_t)ot.n_tasks);
-    hipError_t err = hipSuccess;
-    if (oc.n_tasks > 0) {
-        err = hipMemcpyAsync(pc.data(), d_pc, sizeof(double) * pc.size(), hipMemcpyDeviceToHost, e.stream);
-        if (err == hipSuccess) err = hipMemcpyAsync(pt.data(), d_pt, sizeof(double) * pt.size(), hipMemcpyDeviceToHost, e.stream);
-        if (err == hipSuccess) err = hipMemcpyAsync(cnc.data(), d_nc, sizeof(int32_t) * cnc.size(), hipMemcpyDeviceToHost, e.stream);
-        if (err == hipSuccess) err = hipMemcpyAsync(cnt.data(), d_nt, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost, e.stream);
-        if (err == hipSuccess) err = hipMemcpyAsync(tc.data(), oc.tasks, sizeof(Task) * tc.size(), hipMemcpyDeviceToHost, e.stream);
-        if (err == hipSuccess) err = hipMemcpyAsync(tt.data(), ot.tasks, sizeof(Task) * tt.size(), hipMemcpyDeviceToHost, e.stream);
-    }
-    if (err == hipSuccess && d_corner)
-        err = hipMemcpyAsync(per_corner, d_corner, sizeof(double) * 8 * e.n_obs, hipMemcpyDeviceToHost, e.stream);
-    if (err == hipSuccess)
-        err = hipStreamSynchronize(e.stream);
-    (void)hipFree(d_pc);
-    (void)hipFree(d_pt);
-    (void)hipFree(d_nc);
-    (void)hipFree(d_nt);
-    if (d_corner)
-        (void)hipFree(d_corner);
-    if (err != hipSuccess) {
-        set_error(std::string("reprojection_stats: ") + hipGetErrorString(err));
-        return VMM_BA_ERR_HIP;
-    }
-    // per-pose means in task order (the reference accumulates in observation order,
-    // src/TagReconstructor.cpp:344-368; the value differs only in summation order)
-    std::vector<double> sc((size_t)e.n_cams, 0.0), st((size_t)e.n_tags, 0.0);
-    std::vector<int64_t> nc((size_t)e.n_cams, 0), nt((size_t)e.n_tags, 0);
-    for (size_t k = 0; k < tc.size(); ++k) {
-        sc[tc[k].pose] += pc[k];
-        nc[tc[k].pose] += 4 * (int64_t)cnc[k];   // active observations only
-    }
-    for (size_t k = 0; k < tt.size(); ++k) {
-        st[tt[k].pose] += pt[k];
-        nt[tt[k].pose] += 4 * (int64_t)cnt[k];
-    }
+        HIP_TRY(hipMemcpyAsync(per_corner, e.stats_corner, sizeof(double) * 8 * e.n_obs, hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    const double* sc = pose.data();
+    const double* st = sc + e.n_cams;
+    const double* nc = sc + n_pose;
+    const double* nt = nc + e.n_cams;
     if (per_cam_mean)
         for (int c = 0; c < e.n_cams; ++c)
-            per_cam_mean[c] = nc[c] ? sc[c] / (double)nc[c] : -1.0;   // :379-383
-    double a = 0.0;
-    int64_t tot = 0;
+            per_cam_mean[c] = nc[c] > 0.0 ? sc[c] / nc[c] : -1.0;   // :371-383
+    double a = 0.0, tot = 0.0;
     for (int t = 0; t < e.n_tags; ++t) {
-        if (nt[t]) {
+        if (nt[t] > 0.0) {
             a += st[t];
             tot += nt[t];
         }
         if (per_tag_mean)
-            per_tag_mean[t] = nt[t] ? st[t] / (double)nt[t] : NAN;
+            per_tag_mean[t] = nt[t] > 0.0 ? st[t] / nt[t] : NAN;
     }
     if (avg)
-        *avg = tot ? a / (double)tot : 0.0;                            // :416-426
+        *avg = tot > 0.0 ? a / tot : 0.0;                            // :416-426
     return VMM_BA_OK;
 }
 

@@ -65,7 +65,9 @@ def quat_from_R(R):
 
 
 def project(X, R, t, intr, dist):
-    """Pixel projection of world points X (n,3) -- the CameraModel::projectPoint arithmetic, vectorised."""
+    """Pixel projection of world points X (n,3) with OpenCV's distortion model (cv::projectPoints, the model
+    solvePnP minimises; /root/reference/src/EigenCVConversions.cpp:38-106 calls OpenCV).  Deliberately NOT
+    CameraModel::projectPoint, whose y tangential term uses the already distorted x (src/CameraModel.cpp:20-23)."""
     fx, fy, cx, cy = intr
     k1, k2, p1, p2, k3 = dist
     P = X @ R.T + t

@@ -125,7 +125,8 @@ class CameraModel:
         return K
 
     def projectPoint(self, point3D, device=0):
-        """CameraModel::projectPoint, src/CameraModel.cpp:6-26: camera-frame point(s) -> pixel(s).
+        """CameraModel::projectPoint, src/CameraModel.cpp:6-26: camera-frame point(s) -> pixel(s), including the
+        reference's aliasing at :20-23 (the y tangential term is evaluated with the already distorted x).
 
         Accepts one point (3,) or a batch (n, 3); evaluated by the device kernel.
         """
