@@ -88,6 +88,71 @@ def test_cholesky_reports_indefinite_matrix(eng):
     A[50, 50] = -1.0
     _, info = eng.dense_spd_solve(A, np.ones(70))
     assert info != 0
+    # several blocks: the failed pivot of block 6 must reach the end of the dataflow factorisation (NaN poisoning)
+    rng = np.random.default_rng(9)
+    n = 700
+    B = rng.standard_normal((n, n))
+    A = B @ B.T + n * np.eye(n)
+    A[400, 400] = -1.0
+    _, info = eng.dense_spd_solve(A, np.ones(n))
+    assert info != 0
+    # ... and the next factorisation on the same process is clean again
+    A[400, 400] = 5.0 * n
+    x, info = eng.dense_spd_solve(A, np.ones(n))
+    assert info == 0
+    np.testing.assert_allclose(x, np.linalg.solve(A, np.ones(n)), rtol=0, atol=1e-10 * np.abs(x).max())
+
+
+@pytest.mark.parametrize("env", [{"VMM_BA_NO_DATAFLOW": "1"}, {"VMM_BA_NO_CHAIN": "1"}])
+def test_cholesky_fallback_paths(eng, monkeypatch, env):
+    """One k_chol_step launch per block column (reduced systems of more than 21 blocks take this path) and the
+    per-block back-substitution kernels, forced at a size the dataflow kernel would otherwise handle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(12)
+    for n in (333, 1200):
+        B = rng.standard_normal((n, n))
+        A = B @ B.T + n * np.eye(n)
+        b = rng.standard_normal(n)
+        x, info = eng.dense_spd_solve(A, b)
+        assert info == 0
+        ref = np.linalg.solve(A, b)
+        np.testing.assert_allclose(x, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+        x2, _ = eng.dense_spd_solve(A, b)
+        np.testing.assert_array_equal(x, x2)
+
+
+@pytest.mark.parametrize("n", [2048, 6000])
+def test_cholesky_large_orders(eng, n):
+    """More than 21 blocks: the looping trailing-update workgroups of k_chol_step (several tiles per workgroup from
+    about 22 blocks on: asm-requested operands, LDS ping-pong) -- the path behind the 2000 x 1000 figures."""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n // 4))
+    A = B @ B.T + np.diag(rng.uniform(1.0, 2.0, n)) * n
+    b = rng.standard_normal(n)
+    x, info = eng.dense_spd_solve(A, b)
+    assert info == 0
+    ref = np.linalg.solve(A, b)
+    np.testing.assert_allclose(x, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    x2, info2 = eng.dense_spd_solve(A, b)
+    assert info2 == 0
+    np.testing.assert_array_equal(x, x2)
+
+
+@pytest.mark.parametrize("no_xcd", ["0", "1"])
+def test_syrk_many_tiles(eng, monkeypatch, no_xcd):
+    """n = 4096: 528 tiles >= 512 workgroup slots, so the plan runs a full XCD-aware round of one tile per
+    workgroup plus a stream-K remainder; VMM_BA_SYRK_NO_XCD=1 = the pure stream-K split."""
+    monkeypatch.setenv("VMM_BA_SYRK_NO_XCD", no_xcd)
+    rng = np.random.default_rng(21)
+    Z = np.round(rng.standard_normal((64, 4096)) * 3.0)   # integer-valued: exact in f64, any summation order
+    Cg = eng.dense_syrk(Z)
+    np.testing.assert_array_equal(Cg, Z.T @ Z)
+    Zr = rng.standard_normal((100, 4096))
+    Cr = eng.dense_syrk(Zr)
+    ref = Zr.T @ Zr
+    np.testing.assert_allclose(Cr, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    np.testing.assert_array_equal(Cr, eng.dense_syrk(Zr))
 
 
 def test_project_points_matches_oracle(eng, oracle, kats):

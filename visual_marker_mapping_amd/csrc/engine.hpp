@@ -130,6 +130,8 @@ struct Engine {
     unsigned* flags = nullptr;      // [256] unused + [1] epoch word of the chained back-substitution
     unsigned long long* gran = nullptr;   // [2 * ld] {epoch, 32 value bits} granules of the chain's hand-offs
     bool no_chain = false;          // VMM_BA_NO_CHAIN=1: per-block back-substitution kernels
+    unsigned long long* df_gran = nullptr;   // published 64x8 slices of the dataflow factorisation (<= 21 blocks)
+    bool no_dataflow = false;       // VMM_BA_NO_DATAFLOW=1: one k_chol_step launch per block column
     double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)
     double* step_comm = nullptr;    // [6*n_e + 2]: delta of the eliminated family | cross term
     double* cost_comm = nullptr;    // [2] candidate cost (all-reduced)
@@ -183,6 +185,7 @@ void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int
 // kernels_chol.hip
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl);
 void launch_chol_inverse(Engine& e, int k);
+int dataflow_workgroups(int n_blk);   // workgroups of k_chol_dataflow (must all fit on the chip at one per CU)
 // kernels_cov.hip
 void launch_cov_prepare(Engine& e);
 void launch_cov_rhs(Engine& e, double* B, int ldb, bool identity_rhs);

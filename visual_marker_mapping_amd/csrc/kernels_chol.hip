@@ -116,11 +116,14 @@ __device__ __forceinline__ void chol8(const double* __restrict__ D, Piv8& p)
     }
 }
 
+// gs != nullptr (dataflow factorisation): wave 1 also publishes its eight scaled columns as self-validating
+// {epoch, 32 bits} granules, slice layout [half][column][row] (one 512-byte store instruction per half column).
 template <int J0, bool HAS_T>
 __device__ __forceinline__ void panel_round(const int w, const int lane,
                                             double4_t (&Dacc)[4], double4_t (&Tacc)[4], double* __restrict__ Pd,
                                             double* __restrict__ Pt, double* __restrict__ At,
-                                            double* __restrict__ R, double* __restrict__ invd, bool& ok)
+                                            double* __restrict__ R, double* __restrict__ invd, bool& ok,
+                                            unsigned long long* gs = nullptr, const unsigned epoch = 0u)
 {
     constexpr int tc = J0 >> 4, cj = J0 & 15;
     const int fr = lane & 15, fk = lane >> 4;
@@ -195,6 +198,17 @@ __device__ __forceinline__ void panel_round(const int w, const int lane,
             for (int q = 0; q < 8; ++q) {
                 row[q] = x[q];
                 rr[q] = x[q];
+            }
+            if (gs) {
+                const unsigned long long tag = (unsigned long long)epoch << 32;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(x[q]);
+                    __hip_atomic_store(gs + q * 64 + lane, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(gs + 512 + q * 64 + lane, tag | (bits >> 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -648,8 +662,13 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
                                                          unsigned* epoch_word, const double* __restrict__ Ld,
                                                          const double* __restrict__ Linv)
 {
-    if (ctl->done || ctl->lin_fail)
+    if (ctl->done || ctl->lin_fail) {
+        // the factorisation before this launch may have tagged granules with the current epoch: retire it even
+        // when the solve is skipped (every workgroup of this launch leaves here, so nobody needs the old value)
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+            *epoch_word = *epoch_word + 1u;
         return;
+    }
     __shared__ double L[64 * kLd];
     __shared__ double red[4][64];
     __shared__ double ws[64];
@@ -782,19 +801,10 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
 // which then needs a 64x64 GEMV per block instead of 16 dependent 4x4 solves).  One wave, thread c
 // solves L x = e_c; entries above row c are zero, so all lanes run the same 2016 multiply-adds.
 // Runs as one extra workgroup of a later launch, beside the latency-bound panel: free.
-__device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, const double* __restrict__ dinvk,
-                                                double* __restrict__ Linvk, double* smem)
+// L (row stride kLd, upper part zero) and di (reciprocal diagonal) already in LDS; wave 0 computes.
+__device__ __forceinline__ void chol_inverse_lds(const double* L, const double* di, double* __restrict__ Linvk)
 {
-    double* L = smem;
-    double* di = smem + 64 * kLd;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        L[r * kLd + c] = (c <= r) ? Ldk[idx] : 0.0;
-    }
-    if (tid < 64)
-        di[tid] = dinvk[tid];
-    __syncthreads();
     if (tid >= 64)
         return;
     const int c = tid;
@@ -816,6 +826,286 @@ __device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, 
         x[i] = (i == c) ? di[i] : ((i < c) ? 0.0 : -s * di[i]);
         Linvk[i * 64 + c] = x[i];
     }
+}
+
+__device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, const double* __restrict__ dinvk,
+                                                double* __restrict__ Linvk, double* smem)
+{
+    double* L = smem;
+    double* di = smem + 64 * kLd;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        L[r * kLd + c] = (c <= r) ? Ldk[idx] : 0.0;
+    }
+    if (tid < 64)
+        di[tid] = dinvk[tid];
+    __syncthreads();
+    chol_inverse_lds(L, di, Linvk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dataflow factorisation: the whole Cholesky of a reduced system of up to 21 blocks (order <= 1344: 224 kept
+// poses) in ONE launch.  Every (block column j, row block R > j) pair is a workgroup that keeps its two 64x64
+// blocks -- a replica of the diagonal block (j,j) and the block (R,j) -- in MFMA accumulators from the first to
+// the last instruction (left-looking): it first subtracts the contributions of the panels k < j, eight columns
+// at a time, as those columns are published by the workgroups (k,j) and (k,R), then factors its own panel like
+// the panel workgroup of k_chol_step (eight rounds of eight columns, rows below scaled in the same rounds) and
+// publishes its scaled columns round by round.  One more workgroup per block column holds only the diagonal
+// block; it writes the diagonal factor, its reciprocals and its inverse (back-substitution, covariance).
+//
+// A published slice (64 rows x 8 columns) travels as self-validating {epoch, 32 value bits} granules
+// (cdna_hip_programming.md Guideline 16, R2: the data is the flag): layout [half][column][row], written by ONE
+// wave with one aligned agent-scope 8-byte store per granule, swept by the consumers with agent-scope loads
+// until every tag carries this factorisation's epoch.  Nothing else is shared inside the launch: S is read at
+// the start (written by the previous kernel) and L, Ld, dinv, Linv are written for the kernels that follow.
+//
+// What this buys at 19 blocks: the accumulators never leave the registers between panels (no load / rank-64
+// update / store per step: 9.4 of the 21 us of a k_chol_step), the update of column j+1 by panel j is applied
+// eight columns behind the panel's own rounds on OTHER compute units, and the 19 launch boundaries go.  The
+// critical path is the chain of 8-column rounds plus one slice hand-off per block column.
+//
+// Progress: blockIdx is panel-major, so a workgroup only waits for workgroups with smaller blockIdx; with the
+// in-order dispatch observed on this hardware the earliest unfinished workgroup is always resident and never
+// waits for an undispatched one, whatever the residency (the launcher still only uses this kernel when all
+// workgroups fit on the chip at one per CU).  Every spin is bounded and a timeout raises an abort word that
+// ends every other spin; the factorisation is then reported as failed (NaN poisoning + lin_fail).
+// ------------------------------------------------------------------------------------------------
+constexpr int kDfSlice = 2 * 8 * 64;         // granules (8 bytes each) per published slice
+constexpr unsigned kDfSpinLimit = 1u << 21;   // polls of ~0.3 us each before giving up
+constexpr int kDfXs = 8 * kLdsRow;            // doubles per staged slice, k-major [8][kLdsRow]
+constexpr int kDfSmem = 64 * kLdT + 4 * 64 * kPs + 64 + 4 * kDfXs + 64 * kLd + 64;   // doubles: 107 KB, one workgroup per CU
+
+struct DfArgs {
+    LmCtl* ctl;
+    double* S;
+    int ld, n_pad, n_blk;
+    double* dinv;
+    double* Ld;
+    double* Linv;
+    unsigned long long* G;       // [n_blk (n_blk + 1) / 2][8][kDfSlice]
+    const unsigned* epoch_word;  // bumped by the back-substitution chain that follows
+    unsigned* abort_word;        // == epoch: some workgroup gave up waiting
+};
+
+struct DfQuarter {   // one wave's share of a slice: columns 2v and 2v+1, low and high granules
+    unsigned long long a0, a1, b0, b1;
+};
+
+__device__ __forceinline__ void df_issue(const unsigned long long* sl, const int v, const int lane, DfQuarter& q)
+{
+    q.a0 = __hip_atomic_load(sl + (2 * v) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q.a1 = __hip_atomic_load(sl + 512 + (2 * v) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q.b0 = __hip_atomic_load(sl + (2 * v + 1) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q.b1 = __hip_atomic_load(sl + 512 + (2 * v + 1) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool df_valid(const DfQuarter& q, const unsigned epoch)
+{
+    return (unsigned)(q.a0 >> 32) == epoch && (unsigned)(q.a1 >> 32) == epoch && (unsigned)(q.b0 >> 32) == epoch
+        && (unsigned)(q.b1 >> 32) == epoch;
+}
+
+__device__ __forceinline__ double df_value(const unsigned long long lo, const unsigned long long hi)
+{
+    return __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
+}
+
+// Waits until this wave's quarter(s) of the slice(s) carry the epoch.  The registers hold a first attempt
+// (requested one round ahead); while the slice is not there yet ONE lane polls ONE granule with a sleep in
+// between (MI355X_MICROARCH.md polling-cost), then the quarter is swept again.  Wave-uniform result.
+template <bool HAS_T>
+__device__ __forceinline__ bool df_wait(const unsigned long long* sJ, const unsigned long long* sR, const int v,
+                                        const int lane, const unsigned epoch, const unsigned* abort_word,
+                                        DfQuarter& qJ, DfQuarter& qR)
+{
+    for (unsigned n = 0;;) {
+        const bool ok = df_valid(qJ, epoch) && (!HAS_T || df_valid(qR, epoch));
+        if (__all(ok))
+            return true;
+        // probe: the last granule this wave needs from each slice
+        for (;;) {
+            const unsigned long long pj
+                = __hip_atomic_load(sJ + 512 + (2 * v + 1) * 64 + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long pr = HAS_T
+                ? __hip_atomic_load(sR + 512 + (2 * v + 1) * 64 + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                : pj;
+            if ((unsigned)(pj >> 32) == epoch && (unsigned)(pr >> 32) == epoch)
+                break;
+            if (++n > kDfSpinLimit)
+                return false;
+            if ((n & 63u) == 0u
+                && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)
+                return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (++n > kDfSpinLimit)
+            return false;
+        df_issue(sJ, v, lane, qJ);
+        if (HAS_T)
+            df_issue(sR, v, lane, qR);
+    }
+}
+
+template <bool HAS_T>
+__device__ __forceinline__ void df_role(const DfArgs& a, const int j, const int R, double* smem)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int K0 = j * kNB;
+    const int R0 = R * kNB;
+    const int n_blk = a.n_blk, ld = a.ld, n_pad = a.n_pad;
+    const unsigned epoch = *a.epoch_word + 1u;
+    double* RA = smem;                       // D-only role: L^T (stride kLdT); others: result tile (stride kLd)
+    double* Pd = RA + 64 * kLdT;
+    double* Pt = Pd + 2 * 64 * kPs;
+    double* invd = Pt + 2 * 64 * kPs;
+    double* Xs = invd + 64;                  // [2 buffers][J | R][8][kLdsRow]
+    double* Li = Xs + 4 * kDfXs;             // diagonal factor, row stride kLd (inverse)
+    double* di = Li + 64 * kLd;
+    __shared__ int s_timeout;
+    if (tid == 0)
+        s_timeout = 0;
+    const double* __restrict__ S = a.S;
+    double4_t Dacc[4], Tacc[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+        Dacc[tj] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+        Tacc[tj] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * w + fk + 4 * r;
+            const double dv = S[(int64_t)(K0 + row) * ld + K0 + 16 * tj + fr];
+            Dacc[tj][r] = (tj <= w) ? dv : 0.0;
+            if (HAS_T) {
+                const int grow = (R0 + row <= n_pad) ? R0 + row : n_pad;   // clamp: always in bounds
+                const double tv = S[(int64_t)grow * ld + K0 + 16 * tj + fr];
+                Tacc[tj][r] = (R0 + row <= n_pad) ? tv : 0.0;
+            }
+        }
+    }
+    // slices of panel k: row blocks k+1 .. n_blk, eight rounds each
+    auto slice = [&](int k, int rb, int r) -> unsigned long long* {
+        const int64_t base = (int64_t)k * n_blk - (int64_t)k * (k - 1) / 2 + (rb - k - 1);
+        return a.G + (base * 8 + r) * kDfSlice;
+    };
+    // 1. the panels before mine, eight columns per step, as they are published
+    const int n_it = 8 * j;
+    __syncthreads();   // s_timeout
+    if (n_it > 0) {
+        DfQuarter qJ, qR;
+        df_issue(slice(0, j, 0), w, lane, qJ);
+        if (HAS_T)
+            df_issue(slice(0, R, 0), w, lane, qR);
+        else
+            qR = qJ;
+        for (int it = 0; it < n_it; ++it) {
+            const int k = it >> 3, r = it & 7;
+            const unsigned long long* sJ = slice(k, j, r);
+            const unsigned long long* sR = HAS_T ? slice(k, R, r) : sJ;
+            const bool got = df_wait<HAS_T>(sJ, sR, w, lane, epoch, a.abort_word, qJ, qR);
+            double* XJ = Xs + (it & 1) * 2 * kDfXs;
+            double* XR = XJ + kDfXs;
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            XJ[(2 * w) * kLdsRow + lane] = got ? df_value(qJ.a0, qJ.a1) : nan;
+            XJ[(2 * w + 1) * kLdsRow + lane] = got ? df_value(qJ.b0, qJ.b1) : nan;
+            if (HAS_T) {
+                XR[(2 * w) * kLdsRow + lane] = got ? df_value(qR.a0, qR.a1) : nan;
+                XR[(2 * w + 1) * kLdsRow + lane] = got ? df_value(qR.b0, qR.b1) : nan;
+            }
+            if (!got && lane == 0) {
+                s_timeout = 1;
+                __hip_atomic_store(a.abort_word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (it + 1 < n_it) {   // the next slice is requested before this one is applied
+                const int k2 = (it + 1) >> 3, r2 = (it + 1) & 7;
+                df_issue(slice(k2, j, r2), w, lane, qJ);
+                if (HAS_T)
+                    df_issue(slice(k2, R, r2), w, lane, qR);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = (ks * 4 + fk) * kLdsRow;
+                const double ad = -XJ[row + 16 * w + fr];
+                const double at = HAS_T ? -XR[row + 16 * w + fr] : 0.0;
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+                    const double b = XJ[row + 16 * tj + fr];
+                    const double adm = (tj <= w) ? ad : 0.0;
+                    Dacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(adm, b, Dacc[tj], 0, 0, 0);
+                    if (HAS_T)
+                        Tacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, b, Tacc[tj], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // 2. my own panel; the rows below leave round by round
+    bool ok = true;
+    unsigned long long* g0 = HAS_T ? slice(j, R, 0) : nullptr;
+    panel_round<0, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, g0, epoch);
+    panel_round<8, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 1 * kDfSlice : nullptr, epoch);
+    panel_round<16, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 2 * kDfSlice : nullptr, epoch);
+    panel_round<24, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 3 * kDfSlice : nullptr, epoch);
+    panel_round<32, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 4 * kDfSlice : nullptr, epoch);
+    panel_round<40, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 5 * kDfSlice : nullptr, epoch);
+    panel_round<48, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 6 * kDfSlice : nullptr, epoch);
+    panel_round<56, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 7 * kDfSlice : nullptr, epoch);
+    __syncthreads();
+    // 3. results for the kernels after this launch
+    if (!HAS_T) {
+        if (tid < 64)
+            a.dinv[K0 + tid] = invd[tid];
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int r = idx >> 6, c = idx & 63;
+            const double v = (c <= r) ? RA[c * kLdT + r] : 0.0;
+            if (c <= r)
+                a.Ld[(int64_t)j * 4096 + r * 64 + c] = v;
+            Li[r * kLd + c] = v;
+        }
+        if (tid < 64)
+            di[tid] = invd[tid];
+        __syncthreads();
+        if (j < n_blk - 1)   // the chain solves the last block directly
+            chol_inverse_lds(Li, di, a.Linv + (int64_t)j * 4096);
+        return;
+    }
+    for (int idx = tid; idx < 64 * 32; idx += 256) {
+        const int rr = idx >> 5, c = (idx & 31) * 2;
+        if (R0 + rr <= n_pad)
+            *reinterpret_cast<double2*>(a.S + (int64_t)(R0 + rr) * ld + K0 + c)
+                = make_double2(RA[rr * kLd + c], RA[rr * kLd + c + 1]);
+    }
+    // the last panel's row block (the rhs row) closes the factorisation: a failed pivot anywhere has reached it
+    // as NaN through the published columns; a timeout anywhere through the abort word
+    if (j == n_blk - 1 && tid == 0) {
+        const bool aborted = __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+        if (!ok || s_timeout || aborted)
+            a.ctl->lin_fail = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chol_dataflow(const DfArgs a)
+{
+    if (a.ctl->done || a.ctl->lin_fail)
+        return;
+    __shared__ __attribute__((aligned(16))) double smem[kDfSmem];
+    // blockIdx -> (block column j, role): the row blocks j+1 .. n_blk first, the diagonal-only role last
+    int b = (int)blockIdx.x, j = 0;
+    for (; j < a.n_blk; ++j) {
+        const int cnt = a.n_blk - j + 1;
+        if (b < cnt)
+            break;
+        b -= cnt;
+    }
+    if (j >= a.n_blk)
+        return;
+    if (b < a.n_blk - j)
+        df_role<true>(a, j, j + 1 + b, smem);
+    else
+        df_role<false>(a, j, j, smem);
 }
 
 // One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their
@@ -864,9 +1154,32 @@ static int update_tiles(int n_blk, int k)   // tiles of the trailing update of p
     return tiles;
 }
 
+int dataflow_workgroups(int n_blk) { return n_blk * (n_blk + 1) / 2 + n_blk; }
+
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl)
 {
     const int n_blk = n_pad / kNB;
+    const bool chain = n_blk <= e.n_cu && e.flags && e.gran && !e.no_chain;
+    if (chain && e.df_gran && !e.no_dataflow && dataflow_workgroups(n_blk) <= e.n_cu) {
+        // one launch for the factorisation + forward substitution, one for the back-substitution chain (which
+        // bumps the epoch both kernels tag their granules with)
+        DfArgs a;
+        a.ctl = ctl;
+        a.S = S;
+        a.ld = ld;
+        a.n_pad = n_pad;
+        a.n_blk = n_blk;
+        a.dinv = e.dinv;
+        a.Ld = e.Ldiag;
+        a.Linv = e.Linv;
+        a.G = e.df_gran;
+        a.epoch_word = e.flags + 256;
+        a.abort_word = e.flags + 257;
+        hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(n_blk)), dim3(256), 0, e.stream, a);
+        hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
+                           e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
+        return;
+    }
     for (int k = 0; k < n_blk; ++k) {
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
         const int n_panel = 1 + (rows_below + 63) / 64;
@@ -887,7 +1200,7 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
     }
     // one chained launch while every workgroup of the chain is certainly resident (one per CU); the per-block
     // kernels otherwise
-    if (n_blk <= e.n_cu && e.flags && e.gran && !e.no_chain) {
+    if (chain) {
         hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
                            e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
     } else {

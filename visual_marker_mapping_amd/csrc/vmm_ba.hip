@@ -533,6 +533,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         e.use_graph = !(ng && ng[0] == '1');
         const char* nc = getenv("VMM_BA_NO_CHAIN");
         e.no_chain = nc && nc[0] == '1';
+        const char* nd = getenv("VMM_BA_NO_DATAFLOW");
+        e.no_dataflow = nd && nd[0] == '1';
     }
     e.K.fx = p->intr[0]; e.K.fy = p->intr[1]; e.K.cx = p->intr[2]; e.K.cy = p->intr[3];
     e.K.k1 = p->dist[0]; e.K.k2 = p->dist[1]; e.K.p1 = p->dist[2]; e.K.p2 = p->dist[3]; e.K.k3 = p->dist[4];
@@ -634,6 +636,9 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.Linv, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
     if ((rc = dev_alloc(e, &e.flags, 260))) return fail(rc);
     if ((rc = dev_alloc(e, &e.gran, (size_t)2 * e.ldz))) return fail(rc);
+    if (!e.no_dataflow && dataflow_workgroups(e.n_blk) <= e.n_cu
+        && (rc = dev_alloc(e, &e.df_gran, (size_t)e.n_blk * (e.n_blk + 1) / 2 * 8 * 1024)))
+        return fail(rc);
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.step_comm, (size_t)6 * e.n_e + 2))) return fail(rc);
     if ((rc = dev_alloc(e, &e.cost_comm, 2))) return fail(rc);
@@ -1023,6 +1028,13 @@ static int make_scratch(Engine& e, int device, int ld)
     if ((rc = dev_alloc(e, &e.flags, 260))) return rc;
     if ((rc = dev_alloc(e, &e.gran, (size_t)2 * ld))) return rc;
     { const char* nc = getenv("VMM_BA_NO_CHAIN"); e.no_chain = nc && nc[0] == '1'; }
+    { const char* nd = getenv("VMM_BA_NO_DATAFLOW"); e.no_dataflow = nd && nd[0] == '1'; }
+    {
+        const int nb = ld / kNB - 1;   // ld = n_pad + 64
+        if (!e.no_dataflow && dataflow_workgroups(nb) <= e.n_cu
+            && (rc = dev_alloc(e, &e.df_gran, (size_t)nb * (nb + 1) / 2 * 8 * 1024)))
+            return rc;
+    }
     if ((rc = dev_alloc(e, &e.ctl, 1))) return rc;
     return VMM_BA_OK;
 }
