@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--visibility", type=float, default=1.0)
     ap.add_argument("--poll", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collective", choices=["rccl", "callback"], default="rccl",
+                    help="N > 1: 'rccl' = the library's own ncclAllReduce recorded into the iteration graph "
+                         "(vmm_ba_enable_rccl); 'callback' = host callback into torch.distributed per collective")
     ap.add_argument("--elimination", choices=["auto", "cams", "tags"], default="auto")
     ap.add_argument("--precision", choices=["f64", "f32"], default=None,
                     help="f32 = J^T J blocks accumulated/stored in f32, everything else f64 (default for --config 4, "
@@ -104,7 +107,10 @@ def main():
                             precision=eng.PRECISION_F32_ACCUM if precision == "f32" else eng.PRECISION_F64)
     setup_s = time.time() - t0
     if use_dist:
-        ba.set_allreduce(vdist.make_allreduce(local_rank))
+        if a.collective == "rccl":
+            vdist.enable_native_rccl(ba, rank)             # ncclAllReduce inside the iteration's hipGraph
+        else:
+            ba.set_allreduce(vdist.make_allreduce(local_rank))   # host callback -> torch.distributed
     robust = 1 if s.robustify else 0
     opts_kw = dict(robustify=robust, poll_interval=a.poll)
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VMM_BA_ABI_VERSION 1
+#define VMM_BA_ABI_VERSION 2
 
 typedef struct vmm_ba_handle_s* vmm_ba_handle;
 
@@ -142,6 +142,14 @@ typedef struct vmm_ba_summary {
     vmm_ba_iteration* trace;        /* optional caller buffer, filled up to trace_capacity rows */
     int32_t trace_capacity;
     int32_t reserved;
+    /* Where the device time of the solve went (the per-phase part of Ceres' Summary::FullReport(),
+     * src/TagReconstructor.cpp:741-742), measured ON the device: the first kernel of every group stamps the
+     * 100 MHz s_memrealtime counter and the control kernel sums the differences.  Their sum is <= time_solve_s. */
+    double time_eval_s;             /* residual + Jacobian evaluation, J^T J / J^T r blocks (Ceres: "Jacobian & residual evaluation") */
+    double time_eliminate_s;        /* block elimination, Z, rank-k update, reduced system */
+    double time_factor_solve_s;     /* dense Cholesky + triangular solves (Ceres: "Linear solver") */
+    double time_step_s;             /* back-substitution, candidate, cost at the candidate */
+    double time_control_s;          /* trust-region control kernels */
 } vmm_ba_summary;
 
 /* Sum-all-reduce of `count` doubles in DEVICE memory, in place, ordered on `hip_stream`
@@ -183,6 +191,16 @@ int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt
 int vmm_ba_get_state(vmm_ba_handle h, double* cam_qt, double* tag_qt);
 
 int vmm_ba_set_allreduce(vmm_ba_handle h, vmm_ba_allreduce_fn fn, void* user);
+
+/* Native collective path (BASELINE.json north_star: "RCCL all-reduce over xGMI of the reduced camera system"):
+ * the library resolves librccl.so itself (dlopen) and issues ncclAllReduce(ncclDouble, ncclSum) in place on its
+ * own stream, recorded into the LM iteration's hipGraph, so that world > 1 runs one graph per iteration with no
+ * host callback.  Rank 0 draws an id, the host side hands the same 128 bytes to every rank by whatever means it
+ * has (MPI, torch.distributed, a file), and every rank calls vmm_ba_enable_rccl -- a collective call; rank and
+ * world size are those of vmm_ba_create_options.  Takes precedence over a vmm_ba_set_allreduce callback. */
+#define VMM_BA_RCCL_ID_BYTES 128
+int vmm_ba_rccl_unique_id(void* id128);
+int vmm_ba_enable_rccl(vmm_ba_handle h, const void* id128);
 
 /* Switches observations off and on without rebuilding the handle: mask[i] != 0 keeps observation i (the
  * caller's order), NULL keeps all.  This is how the incremental driver (src/TagReconstructor.cpp:86-278: one

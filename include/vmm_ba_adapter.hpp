@@ -97,6 +97,20 @@ Packed pack(const TagMap& tags, const CamMap& cams, const Detection& det, const 
     return p;
 }
 
+// What the reference prints with summary.FullReport() (src/TagReconstructor.cpp:741-742), as far as it exists
+// here: counts, costs, and where the device time went (measured on the device, vmm_ba_summary.time_*_s).
+inline void printFullReport(const vmm_ba_summary& s)
+{
+    const double accounted = s.time_eval_s + s.time_eliminate_s + s.time_factor_solve_s + s.time_step_s + s.time_control_s;
+    std::cout << "vmm_ba: iterations " << s.iterations << " (successful " << s.num_successful_steps << ", unsuccessful "
+              << s.num_unsuccessful_steps << "), initial cost " << s.initial_cost << ", final cost " << s.final_cost
+              << ", solver time " << s.time_solve_s << " s" << std::endl
+              << "vmm_ba: time (s): residual + Jacobian evaluation " << s.time_eval_s << ", elimination + rank-k update "
+              << s.time_eliminate_s << ", linear solver (Cholesky + triangular solves) " << s.time_factor_solve_s
+              << ", step + candidate cost " << s.time_step_s << ", trust-region control " << s.time_control_s
+              << ", host / idle " << (s.time_solve_s > accounted ? s.time_solve_s - accounted : 0.0) << std::endl;
+}
+
 // Body of TagReconstructor::doBundleAdjustment (src/TagReconstructor.cpp:646-743).  Updates the map
 // nodes in place, prints "Solution <termination_type>" like :740.  Returns the termination type.
 template <class TagMap, class CamMap, class Detection, class CamModel>
@@ -144,8 +158,7 @@ int doBundleAdjustment(TagMap& tags, CamMap& cams, const Detection& det, const C
     }
     std::cout << "Solution " << s.termination_type << std::endl;     // :740
     if (printSummary)                                                 // :741-742 (FullReport stand-in)
-        std::cout << "vmm_ba: iterations " << s.iterations << ", initial cost " << s.initial_cost
-                  << ", final cost " << s.final_cost << ", solver time " << s.time_solve_s << " s" << std::endl;
+        printFullReport(s);
     if (printSummary) {                                               // :761-782
         double avg[3] = { 0.0, 0.0, 0.0 };
         for (size_t k = 0; k < p.tag_ids.size(); ++k) {

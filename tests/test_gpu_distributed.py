@@ -108,3 +108,64 @@ def test_rccl_allreduce_hook_single_rank(tmp_path):
     np.testing.assert_allclose(r["costs"], [t["cost"] for t in ref["trace"]], rtol=1e-12)
     np.testing.assert_allclose(r["cam"], cam, rtol=0, atol=1e-12 * np.abs(cam).max())
     np.testing.assert_allclose(r["tag"], tag, rtol=0, atol=1e-12 * np.abs(tag).max())
+
+
+def _native_rccl_worker(rank, world, port, out, graph):
+    """The library's own RCCL path (vmm_ba_enable_rccl): ncclAllReduce issued in C++ on the engine's stream and, with
+    graph == "1", recorded into the iteration's hipGraph.  One rank, collectives forced on: every all-reduce is the
+    identity, so the solve must equal, bit for bit, the same sharded code path with the host-callback collective."""
+    import torch
+    import torch.distributed as dist
+    os.environ["VMM_BA_FORCE_COLLECTIVES"] = "1"
+    os.environ["VMM_BA_RCCL_GRAPH"] = graph
+    from visual_marker_mapping_amd import distributed as vd
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    s = make_scene(1)
+    res = {}
+    for name in ("callback", "native"):
+        ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                                s.obs_px, device=0, rank=0, world_size=1)
+        if name == "native":
+            vd.enable_native_rccl(ba, rank)
+        else:
+            ba.set_allreduce(vd.make_allreduce(0))
+        o = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+        cam, tag = ba.get_state()
+        cost = ba.cost(robustify=True)
+        ba.set_state(s.cam_init, s.tag_init)
+        o2 = ba.solve(eng.default_options(robustify=1))          # the recorded graph is replayed by the next solve
+        ba.close()
+        res[name] = dict(cam=cam, tag=tag, iters=o["iterations"], costs=[t["cost"] for t in o["trace"]], cost=cost,
+                         again=o2["final_cost"], final=o["final_cost"])
+    np.savez(out, **{"%s_%s" % (n, k): v for n, d in res.items() for k, v in d.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_native_rccl_path_single_rank(tmp_path, graph):
+    mp = pytest.importorskip("torch.multiprocessing")
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    out = str(tmp_path / "native.npz")
+    mp.spawn(_native_rccl_worker, args=(1, _free_port(), out, graph), nprocs=1, join=True)
+    r = np.load(out)
+    # native RCCL == host-callback collective, bit for bit (the same kernels around an identity all-reduce)
+    for k in ("cam", "tag", "iters", "costs", "cost", "again", "final"):
+        np.testing.assert_array_equal(r["native_" + k], r["callback_" + k])
+    assert float(r["native_again"]) == float(r["native_final"])
+    # ... and the single-GPU solve up to summation order (the sharded path sums costs and adds the kept family's
+    # diagonal blocks behind the all-reduce)
+    s = make_scene(1)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                            s.obs_px)
+    ref = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+    cam, tag = ba.get_state()
+    ba.close()
+    assert int(r["native_iters"]) == ref["iterations"]
+    np.testing.assert_allclose(r["native_costs"], [t["cost"] for t in ref["trace"]], rtol=1e-12)
+    np.testing.assert_allclose(r["native_cam"], cam, rtol=0, atol=1e-12 * np.abs(cam).max())
+    np.testing.assert_allclose(r["native_tag"], tag, rtol=0, atol=1e-12 * np.abs(tag).max())

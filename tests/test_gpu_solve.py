@@ -225,3 +225,27 @@ def test_f32_accumulate_precision_reaches_the_f64_optimum(oracle, config):
     with pytest.raises(Exception):
         engine.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px,
                               precision=7)
+
+
+def test_phase_report_accounts_for_the_solve():
+    """vmm_ba_summary.time_*_s (the per-phase part of summary.FullReport(), src/TagReconstructor.cpp:741-742): device
+    time per group measured with in-kernel 100 MHz stamps.  Every phase ran, and together they fit into the wall
+    time of the call."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(2)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                            s.obs_px)
+    try:
+        ba.solve(eng.default_options(robustify=0))            # first call: graph capture
+        ba.set_state(s.cam_init, s.tag_init)
+        out = ba.solve(eng.default_options(robustify=0))
+    finally:
+        ba.close()
+    phases = [out[k] for k in ("time_eval_s", "time_eliminate_s", "time_factor_solve_s", "time_step_s", "time_control_s")]
+    assert all(p > 0.0 for p in phases)
+    assert sum(phases) <= out["time_solve_s"]
+    assert sum(phases) >= 0.5 * out["time_solve_s"]           # the device is busy for most of a solve
+    n = out["num_lm_iterations"]
+    assert 50e-6 * n < out["time_factor_solve_s"] < 1e-3 * n   # the Cholesky dominates: 0.2-0.3 ms per iteration
+    assert out["time_eval_s"] < out["time_factor_solve_s"]

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
     assert set(_lib.EXPORTS) == declared
-    assert L.vmm_ba_abi_version() == 1
+    assert L.vmm_ba_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define VMM_BA_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_default_options_are_the_ceres_defaults_the_reference_runs_with():

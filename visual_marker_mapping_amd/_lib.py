@@ -9,6 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VMM_BA_LIB selects another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("VMM_BA_LIB") or os.path.join(_HERE, "libvmm_ba.so")
 
+ABI_VERSION = 2          # VMM_BA_ABI_VERSION of include/vmm_ba.h
+RCCL_ID_BYTES = 128      # VMM_BA_RCCL_ID_BYTES
 PRECISION_F64, PRECISION_F32_ACCUM = 0, 1
 OK, ERR_ARGUMENT, ERR_HIP, ERR_COLLECTIVE, ERR_STATE, ERR_NUMERIC = 0, 1, 2, 3, 4, 5
 ELIM_AUTO, ELIM_TAGS, ELIM_CAMERAS = 0, 1, 2
@@ -17,7 +19,8 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 # every symbol include/vmm_ba.h declares
 EXPORTS = ["vmm_ba_last_error", "vmm_ba_abi_version", "vmm_ba_default_options",
            "vmm_ba_default_create_options", "vmm_ba_create", "vmm_ba_destroy", "vmm_ba_set_state",
-           "vmm_ba_get_state", "vmm_ba_set_allreduce", "vmm_ba_set_observation_mask", "vmm_ba_solve", "vmm_ba_cost",
+           "vmm_ba_get_state", "vmm_ba_set_allreduce", "vmm_ba_rccl_unique_id", "vmm_ba_enable_rccl",
+           "vmm_ba_set_observation_mask", "vmm_ba_solve", "vmm_ba_cost",
            "vmm_ba_reprojection_stats", "vmm_ba_tag_translation_covariance", "vmm_ba_project_points", "vmm_ba_eval_blocks",
            "vmm_ba_dense_spd_solve", "vmm_ba_dense_syrk", "vmm_ba_time_kernels"]
 
@@ -59,7 +62,9 @@ class Summary(C.Structure):
                 ("num_lm_iterations", C.c_int32), ("num_jacobian_evals", C.c_int32),
                 ("num_cost_evals", C.c_int32), ("elimination", C.c_int32),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("time_solve_s", C.c_double),
-                ("trace", C.POINTER(Iteration)), ("trace_capacity", C.c_int32), ("reserved", C.c_int32)]
+                ("trace", C.POINTER(Iteration)), ("trace_capacity", C.c_int32), ("reserved", C.c_int32),
+                ("time_eval_s", C.c_double), ("time_eliminate_s", C.c_double), ("time_factor_solve_s", C.c_double),
+                ("time_step_s", C.c_double), ("time_control_s", C.c_double)]
 
 
 class KernelTimes(C.Structure):
@@ -90,12 +95,17 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.vmm_ba_last_error.restype = C.c_char_p
         L.vmm_ba_abi_version.restype = C.c_int
+        if L.vmm_ba_abi_version() != ABI_VERSION:
+            raise ImportError("%s has ABI version %d, this binding needs %d: rebuild it"
+                              % (LIB_PATH, L.vmm_ba_abi_version(), ABI_VERSION))
         L.vmm_ba_destroy.restype = None
         L.vmm_ba_destroy.argtypes = [C.c_void_p]
         L.vmm_ba_create.argtypes = [C.POINTER(Problem), C.POINTER(CreateOptions), C.POINTER(C.c_void_p)]
         L.vmm_ba_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.vmm_ba_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.vmm_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.vmm_ba_rccl_unique_id.argtypes = [C.c_void_p]
+        L.vmm_ba_enable_rccl.argtypes = [C.c_void_p, C.c_void_p]
         L.vmm_ba_set_observation_mask.argtypes = [C.c_void_p, C.c_void_p]
         L.vmm_ba_solve.argtypes = [C.c_void_p, C.POINTER(Options), C.POINTER(Summary)]
         L.vmm_ba_cost.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_double)]

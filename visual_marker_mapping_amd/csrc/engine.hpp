@@ -61,7 +61,20 @@ struct LmCtl {
     int32_t num_successful, num_unsuccessful, num_lm_iterations, num_jac_evals, num_cost_evals;
     int32_t trace_capacity, pad0;
     vmm_ba_iteration cur;      // record under construction
+    // phase report (vmm_ba_summary.time_*_s): s_memrealtime (100 MHz) stamps written by thread 0 of the first
+    // kernel of each group -- 0 evaluation, 1 k_iter_begin, 2 k_elim_factor, 3 Cholesky, 4 k_backsub, 5 k_decide --
+    // and their differences accumulated per solve: 0 evaluation, 1 control, 2 eliminate + rank-k update,
+    // 3 factor + triangular solves, 4 step (back-substitution, candidate, cost at the candidate)
+    unsigned long long stamp[6];
+    unsigned long long phase_ticks[5];
 };
+
+// Start-of-group stamp by one thread of the launch (costs one s_memrealtime + one 8-byte store).
+__device__ __forceinline__ void phase_stamp(const LmCtl* ctl, int slot)
+{
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        const_cast<LmCtl*>(ctl)->stamp[slot] = __builtin_amdgcn_s_memrealtime();
+}
 
 // Stream-K decomposition of the rank-k update (kernels_schur.hip): device arrays + sizes.
 struct SyrkPlan {
@@ -79,6 +92,8 @@ struct Engine {
     bool multi = false;             // world > 1 (or forced for tests): staging buffers, eager launches, all-reduces
     vmm_ba_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    void* rccl_comm = nullptr;      // ncclComm_t of vmm_ba_enable_rccl: the all-reduces are ncclAllReduce on `stream`
+    bool rccl_graph = true;         // ... recorded into the iteration's hipGraph (VMM_BA_RCCL_GRAPH=0: enqueued between graphs)
 
     Intrinsics K;
     int n_cams = 0, n_tags = 0, fixed_tag = -1;
@@ -157,12 +172,20 @@ struct Engine {
     int graph_robustify = -1;
     double graph_huber_a = 0.0;
     bool use_graph = true;
-    bool launched_eagerly = false;  // the handle's first iteration is enqueued without capture
+    bool eager_first = false;       // VMM_BA_EAGER_FIRST=1: the handle's first iteration is enqueued without capture
+    bool launched_eagerly = false;
 
     std::vector<void*> allocs;
 };
 
 void set_error(const std::string& s);
+
+// one per .hip file: hipFuncGetAttributes on every kernel (returns the number of failures)
+int preload_eval_kernels();
+int preload_schur_kernels();
+int preload_chol_kernels();
+int preload_lm_kernels();
+int preload_cov_kernels();
 
 // ---- kernel launchers (defined in the .hip files) ----
 // kernels_eval.hip

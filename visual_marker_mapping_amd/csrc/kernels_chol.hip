@@ -19,6 +19,9 @@
 //   * one workgroup inverts the 64x64 diagonal factor of block k-1 for the back-substitution.
 // The back-substitution L^T y = w is ONE launch of n_blk workgroups handing their 64 unknowns on through
 // self-validating granules (k_backsolve_chain); k_backsolve_step is the per-block fallback.
+#include <type_traits>
+#include <utility>
+
 #include "engine.hpp"
 
 namespace vmm {
@@ -116,14 +119,11 @@ __device__ __forceinline__ void chol8(const double* __restrict__ D, Piv8& p)
     }
 }
 
-// gs != nullptr (dataflow factorisation): wave 1 also publishes its eight scaled columns as self-validating
-// {epoch, 32 bits} granules, slice layout [half][column][row] (one 512-byte store instruction per half column).
 template <int J0, bool HAS_T>
 __device__ __forceinline__ void panel_round(const int w, const int lane,
                                             double4_t (&Dacc)[4], double4_t (&Tacc)[4], double* __restrict__ Pd,
                                             double* __restrict__ Pt, double* __restrict__ At,
-                                            double* __restrict__ R, double* __restrict__ invd, bool& ok,
-                                            unsigned long long* gs = nullptr, const unsigned epoch = 0u)
+                                            double* __restrict__ R, double* __restrict__ invd, bool& ok)
 {
     constexpr int tc = J0 >> 4, cj = J0 & 15;
     const int fr = lane & 15, fk = lane >> 4;
@@ -198,17 +198,6 @@ __device__ __forceinline__ void panel_round(const int w, const int lane,
             for (int q = 0; q < 8; ++q) {
                 row[q] = x[q];
                 rr[q] = x[q];
-            }
-            if (gs) {
-                const unsigned long long tag = (unsigned long long)epoch << 32;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned long long bits = (unsigned long long)__double_as_longlong(x[q]);
-                    __hip_atomic_store(gs + q * 64 + lane, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(gs + 512 + q * 64 + lane, tag | (bits >> 32), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
             }
         }
     }
@@ -845,12 +834,12 @@ __device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dataflow factorisation: the whole Cholesky of a reduced system of up to 21 blocks (order <= 1344: 224 kept
-// poses) in ONE launch.  Every (block column j, row block R > j) pair is a workgroup that keeps its two 64x64
-// blocks -- a replica of the diagonal block (j,j) and the block (R,j) -- in MFMA accumulators from the first to
-// the last instruction (left-looking): it first subtracts the contributions of the panels k < j, eight columns
-// at a time, as those columns are published by the workgroups (k,j) and (k,R), then factors its own panel like
-// the panel workgroup of k_chol_step (eight rounds of eight columns, rows below scaled in the same rounds) and
+// Dataflow factorisation (k_chol_dataflow): the whole Cholesky of a reduced system of up to 21 blocks (order
+// <= 1344: 224 kept poses) in ONE launch.  Every (block column j, row block R > j) pair is a workgroup that keeps
+// its two 64x64 blocks -- a replica of the diagonal block (j,j) and the block (R,j) -- in MFMA accumulators from
+// the first to the last instruction (left-looking): it first subtracts the contributions of the panels k < j,
+// eight columns at a time, as those columns are published by the workgroups (k,j) and (k,R), then factors its own
+// panel (eight rounds of eight columns: 8x8 pivot block, rows scaled in the same round, rank-8 update) and
 // publishes its scaled columns round by round.  One more workgroup per block column holds only the diagonal
 // block; it writes the diagonal factor, its reciprocals and its inverse (back-substitution, covariance).
 //
@@ -860,10 +849,34 @@ __device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, 
 // until every tag carries this factorisation's epoch.  Nothing else is shared inside the launch: S is read at
 // the start (written by the previous kernel) and L, Ld, dinv, Linv are written for the kernels that follow.
 //
-// What this buys at 19 blocks: the accumulators never leave the registers between panels (no load / rank-64
-// update / store per step: 9.4 of the 21 us of a k_chol_step), the update of column j+1 by panel j is applied
-// eight columns behind the panel's own rounds on OTHER compute units, and the 19 launch boundaries go.  The
-// critical path is the chain of 8-column rounds plus one slice hand-off per block column.
+// What this buys at 19 blocks against one k_chol_step launch per block column (21 us each): the accumulators
+// never leave the registers between panels (no load / rank-64 update / store per step: 9.4 us), the update of
+// column j+1 by panel j is applied eight columns behind the panel's own rounds on OTHER compute units, and the
+// 19 launch boundaries go.  Measured time line (tools/gpu_df_stamps.sh): 1.05-1.2 us per 8-column round (the
+// pivot chain: 8x8 Cholesky ~1200 cycles + row scaling ~750 + hand-offs), ~3 us from the last round of a block
+// column to the first pivot block of the next (granule latency + the consumer's backlog: a slice costs a worker
+// 26 MFMAs = 0.7 us + operand loads, about the rate at which slices are produced), 11.7 us per block column.
+//
+// Inside a workgroup the waves are specialised:
+//   wave 0 (P0) factors the 8x8 pivot blocks and scales the rows of the diagonal block, nothing else;
+//   wave 1 (P1) does the same for the rows below and publishes them (granules);
+//   waves 2, 3 (W0, W1) own ALL accumulator tiles (13 each: W0 the 10 lower tiles of the diagonal block + 3 of
+//     the block below, W1 the other 13) and issue every MFMA;
+// each wave alone on its SIMD (f64 MFMA and f64 VALU share a SIMD's FP64 pipe: a wave that does both serialises
+// them, two waves on two SIMDs do not).  A round is three barrier-separated phases:
+//   1  W0: rank-8 update of the tile that holds the next pivot block, pivot block -> LDS
+//   2  P0, P1: 8x8 Cholesky                          ||  W0, W1: update + publish the rest of the pivot tile
+//                                                         column, then part of the remaining tiles
+//   3  P0, P1: scale their rows, write them back      ||  W0, W1: the remaining tiles of the update
+// so the update of round r hides behind the chain of round r+1.  While a workgroup consumes the panels before its
+// own, P0/P1 sweep and stage the published slices and W0/W1 apply them.
+//
+// Variants built and measured at 19 blocks, then removed: every wave owning a 16-row strip
+// of both blocks with waves 0/1 also carrying the pivot chain (233 us against 223 us); the pivot waves applying
+// the previous round's rank-8 update to whole columns themselves so that a round is one barrier (rounds 1.45 us:
+// 64 LDS reads + 64 FMAs per lane and round cost more than the wait they remove; 253 us); the pivot waves fixing
+// up only the 8x8 pivot block from an early copy (230 us: the workers' slice backlog, not the pivot chain, sets
+// the pace).
 //
 // Progress: blockIdx is panel-major, so a workgroup only waits for workgroups with smaller blockIdx; with the
 // in-order dispatch observed on this hardware the earliest unfinished workgroup is always resident and never
@@ -888,185 +901,524 @@ struct DfArgs {
     unsigned* abort_word;        // == epoch: some workgroup gave up waiting
 };
 
-struct DfQuarter {   // one wave's share of a slice: columns 2v and 2v+1, low and high granules
-    unsigned long long a0, a1, b0, b1;
-};
-
-__device__ __forceinline__ void df_issue(const unsigned long long* sl, const int v, const int lane, DfQuarter& q)
-{
-    q.a0 = __hip_atomic_load(sl + (2 * v) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    q.a1 = __hip_atomic_load(sl + 512 + (2 * v) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    q.b0 = __hip_atomic_load(sl + (2 * v + 1) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    q.b1 = __hip_atomic_load(sl + 512 + (2 * v + 1) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ bool df_valid(const DfQuarter& q, const unsigned epoch)
-{
-    return (unsigned)(q.a0 >> 32) == epoch && (unsigned)(q.a1 >> 32) == epoch && (unsigned)(q.b0 >> 32) == epoch
-        && (unsigned)(q.b1 >> 32) == epoch;
-}
-
 __device__ __forceinline__ double df_value(const unsigned long long lo, const unsigned long long hi)
 {
     return __longlong_as_double((long long)(((hi & 0xffffffffull) << 32) | (lo & 0xffffffffull)));
 }
 
-// Waits until this wave's quarter(s) of the slice(s) carry the epoch.  The registers hold a first attempt
-// (requested one round ahead); while the slice is not there yet ONE lane polls ONE granule with a sleep in
-// between (MI355X_MICROARCH.md polling-cost), then the quarter is swept again.  Wave-uniform result.
-template <bool HAS_T>
-__device__ __forceinline__ bool df_wait(const unsigned long long* sJ, const unsigned long long* sR, const int v,
-                                        const int lane, const unsigned epoch, const unsigned* abort_word,
-                                        DfQuarter& qJ, DfQuarter& qR)
+#ifdef VMM_STAMPS
+__device__ unsigned long long g_df_stamps[32][64];   // [block column][slot]: s_memrealtime (100 MHz) / s_memtime
+#define DF_RT(slot)                                                                              \
+    do {                                                                                         \
+        if (stamp_on && lane == 0)                                                               \
+            g_df_stamps[stamp_j][slot] = __builtin_amdgcn_s_memrealtime();                       \
+    } while (0)
+#define DF_CY(slot)                                                                              \
+    do {                                                                                         \
+        if (stamp_on && lane == 0)                                                               \
+            g_df_stamps[stamp_j][slot] = __builtin_amdgcn_s_memtime();                           \
+    } while (0)
+extern "C" int vmm_ba_debug_read_df_stamps(unsigned long long* out)
 {
-    for (unsigned n = 0;;) {
-        const bool ok = df_valid(qJ, epoch) && (!HAS_T || df_valid(qR, epoch));
-        if (__all(ok))
-            return true;
-        // probe: the last granule this wave needs from each slice
-        for (;;) {
-            const unsigned long long pj
-                = __hip_atomic_load(sJ + 512 + (2 * v + 1) * 64 + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long pr = HAS_T
-                ? __hip_atomic_load(sR + 512 + (2 * v + 1) * 64 + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                : pj;
-            if ((unsigned)(pj >> 32) == epoch && (unsigned)(pr >> 32) == epoch)
-                break;
-            if (++n > kDfSpinLimit)
-                return false;
-            if ((n & 63u) == 0u
-                && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)
-                return false;
-            __builtin_amdgcn_s_sleep(2);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_df_stamps), sizeof(unsigned long long) * 32 * 64);
+}
+#else
+#define DF_RT(slot)
+#define DF_CY(slot)
+#endif
+
+namespace df2 {
+
+// tile tables: worker 0 = D lower tiles (row-major) + T(0,0..2); worker 1 = T(0,3) + T(1..3, 0..3)
+__device__ __forceinline__ constexpr bool is_t(int wk, int i) { return wk == 0 ? i >= 10 : true; }
+__device__ __forceinline__ constexpr int tile_i(int wk, int i)
+{
+    if (wk == 0)
+        return i >= 10 ? 0 : (i >= 6 ? 3 : (i >= 3 ? 2 : (i >= 1 ? 1 : 0)));
+    return i == 0 ? 0 : 1 + (i - 1) / 4;
+}
+__device__ __forceinline__ constexpr int tile_j(int wk, int i)
+{
+    if (wk == 0)
+        return i >= 10 ? i - 10 : i - tile_i(0, i) * (tile_i(0, i) + 1) / 2;
+    return i == 0 ? 3 : (i - 1) % 4;
+}
+// phase of tile i in the rank-8 update applied during the round of columns J0.. (pivot tile column tc = J0 >> 4):
+// 0 = not touched, 1 = the pivot tile, 2 = its tile column (and the first remaining tiles), 3 = the others
+__device__ __forceinline__ constexpr int phase_of(int wk, int i, int tc, bool has_t)
+{
+    if (is_t(wk, i) && !has_t)
+        return 0;
+    const int tj = tile_j(wk, i), ti = tile_i(wk, i);
+    if (tj < tc)
+        return 0;
+    if (tj == tc)
+        return (!is_t(wk, i) && ti == tc) ? 1 : 2;
+    // remaining tiles: fill phase 2 up to seven tiles per worker (14 MFMAs ~ the 8x8 Cholesky beside it)
+    int n_col = 0, rank = 0;
+    for (int k = 0; k < 13; ++k) {
+        if (is_t(wk, k) && !has_t)
+            continue;
+        if (tile_j(wk, k) == tc && !(!is_t(wk, k) && tile_i(wk, k) == tc))
+            ++n_col;
+        if (tile_j(wk, k) > tc && k < i)
+            ++rank;
+    }
+    return (n_col + rank < 7) ? 2 : 3;
+}
+
+struct Ops {   // MFMA operands of one k-step: A of the diagonal block's tile rows, A of the block below, B
+    double ad[4], at[4], b[4];
+};
+
+// operands of the rank-8 update with the scaled columns in pd / pt (row-major, stride kPs); rows < m are masked
+template <int WK, bool HAS_T>
+__device__ __forceinline__ void load_ops_panel(const double* pd, const double* pt, const int m, const int fr, const int fk,
+                                               Ops (&o)[2])
+{
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 16 * t + fr;
+            const double v = pd[row * kPs + 4 * ks + fk];
+            const double vm = (row >= m) ? v : 0.0;
+            o[ks].b[t] = vm;
+            o[ks].ad[t] = (WK == 0) ? -vm : 0.0;
+            o[ks].at[t] = (HAS_T && (WK == 1 || t == 0)) ? -pt[row * kPs + 4 * ks + fk] : 0.0;
         }
-        if (++n > kDfSpinLimit)
-            return false;
-        df_issue(sJ, v, lane, qJ);
-        if (HAS_T)
-            df_issue(sR, v, lane, qR);
+}
+
+// operands from staged slices (k-major, stride kLdsRow)
+template <int WK, bool HAS_T>
+__device__ __forceinline__ void load_ops_slice(const double* XJ, const double* XR, const int fr, const int fk, Ops (&o)[2])
+{
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = (4 * ks + fk) * kLdsRow + 16 * t + fr;
+            const double v = XJ[off];
+            o[ks].b[t] = v;
+            o[ks].ad[t] = (WK == 0) ? -v : 0.0;
+            o[ks].at[t] = (HAS_T && (WK == 1 || t == 0)) ? -XR[off] : 0.0;
+        }
+}
+
+template <int WK, int I>
+__device__ __forceinline__ void mfma_tile(double4_t (&acc)[13], const Ops (&o)[2])
+{
+    constexpr int ti = tile_i(WK, I), tj = tile_j(WK, I);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const double a = is_t(WK, I) ? o[ks].at[ti] : o[ks].ad[ti];
+        acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, o[ks].b[tj], acc[I], 0, 0, 0);
     }
 }
 
+// columns cj..cj+7 of tile I -> the panel buffers (rows of the diagonal block -> pd, rows below -> pt)
+template <int WK, int I>
+__device__ __forceinline__ void publish_tile(const double4_t (&acc)[13], double* pd, double* pt, const int cj, const int fr,
+                                             const int fk)
+{
+    constexpr int ti = tile_i(WK, I);
+    if (fr >= cj && fr < cj + kPw) {
+        double* dst = (is_t(WK, I) ? pt : pd) + (16 * ti + fk) * kPs + (fr - cj);
+        dst[0] = acc[I][0];
+        dst[4 * kPs] = acc[I][1];
+        dst[8 * kPs] = acc[I][2];
+        dst[12 * kPs] = acc[I][3];
+    }
+}
+
+// one phase of a worker: the tiles of that phase are updated (UPDATE: not in the first round of a panel, whose
+// accumulators are complete) and, in phases 1 and 2, the tiles of the pivot tile column are published
+template <int WK, bool HAS_T, int J0, int PHASE, bool UPDATE, int... Is>
+__device__ __forceinline__ void worker_phase(double4_t (&acc)[13], const Ops (&o)[2], double* pd, double* pt, const int fr,
+                                             const int fk, std::integer_sequence<int, Is...>)
+{
+    constexpr int tc = J0 >> 4;
+    auto one = [&](auto idx) {
+        constexpr int I = decltype(idx)::value;
+        constexpr int ph = phase_of(WK, I, tc, HAS_T);
+        if constexpr (ph == PHASE) {
+            if constexpr (UPDATE)
+                mfma_tile<WK, I>(acc, o);
+            if constexpr (tile_j(WK, I) == tc)
+                publish_tile<WK, I>(acc, pd, pt, J0 & 15, fr, fk);
+        }
+    };
+    (one(std::integral_constant<int, Is>{}), ...);
+}
+
+template <int WK, bool HAS_T, int... Is>
+__device__ __forceinline__ void worker_apply_slice(double4_t (&acc)[13], const Ops (&o)[2], std::integer_sequence<int, Is...>)
+{
+    auto one = [&](auto idx) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (HAS_T || !is_t(WK, I))
+            mfma_tile<WK, I>(acc, o);
+    };
+    (one(std::integral_constant<int, Is>{}), ...);
+}
+
+using Seq13 = std::make_integer_sequence<int, 13>;
+
+template <typename F, int... Is>
+__device__ __forceinline__ void for_tiles(F&& f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// a pivot wave's whole slice: sixteen granules per lane (lane = row)
+struct SliceRegs {
+    unsigned long long lo[8], hi[8];
+};
+
+__device__ __forceinline__ void issue_slice(const unsigned long long* sl, const int lane, SliceRegs& g)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        g.lo[q] = __hip_atomic_load(sl + q * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g.hi[q] = __hip_atomic_load(sl + 512 + q * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ bool slice_valid(const SliceRegs& g, const unsigned epoch)
+{
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        ok = ok && (unsigned)(g.lo[q] >> 32) == epoch && (unsigned)(g.hi[q] >> 32) == epoch;
+    return ok;
+}
+
+// direct: the slice is expected any moment (the panel right before mine): sweep it again instead of probing one
+// granule first
+__device__ __forceinline__ bool wait_slice(const unsigned long long* sl, const int lane, const unsigned epoch,
+                                           const unsigned* abort_word, const bool direct, SliceRegs& g)
+{
+    for (unsigned n = 0;;) {
+        if (__all(slice_valid(g, epoch)))
+            return true;
+        if (!direct) {
+            for (;;) {
+                const unsigned long long pv
+                    = __hip_atomic_load(sl + 512 + 7 * 64 + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(pv >> 32) == epoch)
+                    break;
+                if (++n > kDfSpinLimit)
+                    return false;
+                if ((n & 63u) == 0u
+                    && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)
+                    return false;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        } else {
+            if ((n & 63u) == 63u
+                && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)
+                return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (++n > kDfSpinLimit)
+            return false;
+        issue_slice(sl, lane, g);
+    }
+}
+
+struct Lds {
+    double* RA;     // D-only role: L^T (stride kLdT); others: result tile (stride kLd)
+    double* Pd;     // [2][64][kPs] panel columns of the diagonal block's rows (ping-pong between rounds)
+    double* Pt;     // the same for the rows below
+    double* invd;
+    double* Xs;     // [2 buffers][J | R][8][kLdsRow] staged slices of earlier panels
+    int stamp_j;    // diagnostic build: block column whose (j, j+1) workgroup records time stamps (else -1)
+};
+
+struct SliceMap {
+    unsigned long long* G;
+    int n_blk;
+    __device__ __forceinline__ unsigned long long* at(int k, int rb, int r) const
+    {
+        const int64_t base = (int64_t)k * n_blk - (int64_t)k * (k - 1) / 2 + (rb - k - 1);
+        return G + (base * 8 + r) * kDfSlice;
+    }
+};
+
+// ---- the pivot waves' program: sweeps during the earlier panels, then 8 x (8x8 Cholesky, scale rows) ----
+// Barriers: one per consumed slice, three per round -- the same sequence as worker_path.
+template <int J0, bool HAS_T>
+__device__ __forceinline__ void pivot_round(const int w, const int lane, const Lds& m, bool& ok, unsigned long long* gs,
+                                            const unsigned epoch)
+{
+    double* pdc = m.Pd + ((J0 >> 3) & 1) * 64 * kPs;
+    double* ptc = m.Pt + ((J0 >> 3) & 1) * 64 * kPs;
+    const bool active = w == 0 || HAS_T;
+#ifdef VMM_STAMPS
+    const bool stamp_on = m.stamp_j >= 0 && w == 0;
+    const int stamp_j = m.stamp_j;
+#endif
+    if (J0 == 16) DF_CY(40);
+    __syncthreads();   // phase 1 done: the pivot block is in pdc
+    if (J0 == 16) DF_CY(41);
+    Piv8 p;
+    if (active)
+        chol8(pdc + J0 * kPs, p);
+    if (J0 == 16) DF_CY(42);
+    __syncthreads();   // phase 2 done: all rows of columns J0..J0+7 are in pdc / ptc
+    if (J0 == 16) DF_CY(43);
+    if (active) {
+        double* row = (w == 0 ? pdc : ptc) + lane * kPs;
+        double x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            x[q] = row[q];
+        // x = a L8^{-T}
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            double v = x[q];
+#pragma unroll
+            for (int k = 0; k < q; ++k)
+                v -= x[k] * p.l[tri8(q, k)];
+            x[q] = v * p.inv[q];
+        }
+        if (w == 0) {
+            ok = ok && p.ok;
+            const int r = lane - J0;
+            const bool below = r >= kPw, above = r < 0;
+            if (below) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    row[q] = x[q];
+            }
+            if (!HAS_T) {
+                // keep L^T for the write-back: x below the pivot block, the factor inside, zero above
+                double* At = m.RA;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    double inside = 0.0;
+#pragma unroll
+                    for (int rr = q; rr < 8; ++rr)
+                        inside = (r == rr) ? p.l[tri8(rr, q)] : inside;
+                    At[(J0 + q) * kLdT + lane] = below ? x[q] : (above ? 0.0 : inside);
+                }
+                if (r >= 0 && r < kPw) {
+                    double iv = 0.0;
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr)
+                        iv = (r == rr) ? p.inv[rr] : iv;
+                    m.invd[lane] = iv;
+                }
+            }
+        } else {
+            double* rr = m.RA + lane * kLd + J0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                row[q] = x[q];
+                rr[q] = x[q];
+            }
+            const unsigned long long tag = (unsigned long long)epoch << 32;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(x[q]);
+                __hip_atomic_store(gs + q * 64 + lane, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gs + 512 + q * 64 + lane, tag | (bits >> 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (J0 == 16) DF_CY(44);
+    __syncthreads();   // phase 3 done: the scaled columns are in pdc / ptc
+    if (J0 == 16) DF_CY(45);
+    DF_RT(2 + (J0 >> 3));
+}
+
 template <bool HAS_T>
-__device__ __forceinline__ void df_role(const DfArgs& a, const int j, const int R, double* smem)
+__device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const int lane, const int j, const int R,
+                                           const Lds& m, const SliceMap& sm, const unsigned epoch, int* s_timeout, bool& ok)
+{
+    const int n_it = 8 * j;
+    if (n_it > 0) {
+        SliceRegs g;
+        const bool sweeper = w == 0 || HAS_T;
+        const int my_rb = (w == 0) ? j : R;
+        if (sweeper)
+            issue_slice(sm.at(0, my_rb, 0), lane, g);
+        for (int it = 0; it < n_it; ++it) {
+            const int k = it >> 3, r = it & 7;
+            if (sweeper) {
+                const bool got = wait_slice(sm.at(k, my_rb, r), lane, epoch, a.abort_word, k == j - 1, g);
+                double* X = m.Xs + (it & 1) * 2 * kDfXs + (w == 0 ? 0 : kDfXs);
+                const double nan = __longlong_as_double(0x7ff8000000000000ll);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    X[q * kLdsRow + lane] = got ? df_value(g.lo[q], g.hi[q]) : nan;
+                if (!got && lane == 0) {
+                    *s_timeout = 1;
+                    __hip_atomic_store(a.abort_word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            if (sweeper && it + 1 < n_it)   // the next slice is requested while the workers apply this one
+                issue_slice(sm.at((it + 1) >> 3, my_rb, (it + 1) & 7), lane, g);
+        }
+    }
+#ifdef VMM_STAMPS
+    const bool stamp_on = m.stamp_j >= 0 && w == 0;
+    const int stamp_j = m.stamp_j;
+#endif
+    DF_RT(1);
+    unsigned long long* g0 = HAS_T ? sm.at(j, R, 0) : sm.G;
+    pivot_round<0, HAS_T>(w, lane, m, ok, g0, epoch);
+    pivot_round<8, HAS_T>(w, lane, m, ok, g0 + 1 * kDfSlice, epoch);
+    pivot_round<16, HAS_T>(w, lane, m, ok, g0 + 2 * kDfSlice, epoch);
+    pivot_round<24, HAS_T>(w, lane, m, ok, g0 + 3 * kDfSlice, epoch);
+    pivot_round<32, HAS_T>(w, lane, m, ok, g0 + 4 * kDfSlice, epoch);
+    pivot_round<40, HAS_T>(w, lane, m, ok, g0 + 5 * kDfSlice, epoch);
+    pivot_round<48, HAS_T>(w, lane, m, ok, g0 + 6 * kDfSlice, epoch);
+    pivot_round<56, HAS_T>(w, lane, m, ok, g0 + 7 * kDfSlice, epoch);
+}
+
+// ---- a worker wave's program ----
+template <int WK, int J0, bool HAS_T>
+__device__ __forceinline__ void worker_round(const int lane, double4_t (&acc)[13], const Lds& m)
+{
+    const int fr = lane & 15, fk = lane >> 4;
+    double* pdc = m.Pd + ((J0 >> 3) & 1) * 64 * kPs;
+    double* ptc = m.Pt + ((J0 >> 3) & 1) * 64 * kPs;
+    const double* pdp = m.Pd + (((J0 >> 3) & 1) ^ 1) * 64 * kPs;
+    const double* ptp = m.Pt + (((J0 >> 3) & 1) ^ 1) * 64 * kPs;
+    constexpr bool UPD = J0 > 0;
+#ifdef VMM_STAMPS
+    const bool stamp_on = m.stamp_j >= 0 && WK == 0;
+    const int stamp_j = m.stamp_j;
+#endif
+    Ops o[2];
+    if (J0 == 16) DF_CY(48);
+    if (UPD)
+        load_ops_panel<WK, HAS_T>(pdp, ptp, J0, fr, fk, o);
+    worker_phase<WK, HAS_T, J0, 1, UPD>(acc, o, pdc, ptc, fr, fk, Seq13{});
+    if (J0 == 16) DF_CY(49);
+    __syncthreads();
+    if (J0 == 16) DF_CY(50);
+    worker_phase<WK, HAS_T, J0, 2, UPD>(acc, o, pdc, ptc, fr, fk, Seq13{});
+    if (J0 == 16) DF_CY(51);
+    __syncthreads();
+    if (J0 == 16) DF_CY(52);
+    worker_phase<WK, HAS_T, J0, 3, UPD>(acc, o, pdc, ptc, fr, fk, Seq13{});
+    if (J0 == 16) DF_CY(53);
+    __syncthreads();
+    if (J0 == 16) DF_CY(54);
+}
+
+template <int WK, bool HAS_T>
+__device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, const int j, const int R, const Lds& m)
+{
+    const int fr = lane & 15, fk = lane >> 4;
+    const int K0 = j * kNB, R0 = R * kNB;
+    const int ld = a.ld, n_pad = a.n_pad;
+    const double* __restrict__ S = a.S;
+    // accumulator tiles straight from global memory, in accumulator layout
+    double4_t acc[13];
+    for_tiles([&](auto idx) {
+        constexpr int I = decltype(idx)::value;
+        constexpr int ti = tile_i(WK, I), tj = tile_j(WK, I);
+        acc[I] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+        if constexpr (!is_t(WK, I)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[I][r] = S[(int64_t)(K0 + 16 * ti + fk + 4 * r) * ld + K0 + 16 * tj + fr];
+        } else if constexpr (HAS_T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = R0 + 16 * ti + fk + 4 * r;
+                const int grow = (row <= n_pad) ? row : n_pad;   // clamp: always in bounds
+                const double tv = S[(int64_t)grow * ld + K0 + 16 * tj + fr];
+                acc[I][r] = (row <= n_pad) ? tv : 0.0;
+            }
+        }
+    }, Seq13{});
+    const int n_it = 8 * j;
+    for (int it = 0; it < n_it; ++it) {
+        const double* XJ = m.Xs + (it & 1) * 2 * kDfXs;
+        const double* XR = XJ + kDfXs;
+        __syncthreads();
+        if (WK == 0 || HAS_T) {
+            Ops o[2];
+            load_ops_slice<WK, HAS_T>(XJ, XR, fr, fk, o);
+            for_tiles([&](auto idx) {
+                constexpr int I = decltype(idx)::value;
+                if constexpr (HAS_T || !is_t(WK, I))
+                    mfma_tile<WK, I>(acc, o);
+            }, Seq13{});
+        }
+    }
+    worker_round<WK, 0, HAS_T>(lane, acc, m);
+    worker_round<WK, 8, HAS_T>(lane, acc, m);
+    worker_round<WK, 16, HAS_T>(lane, acc, m);
+    worker_round<WK, 24, HAS_T>(lane, acc, m);
+    worker_round<WK, 32, HAS_T>(lane, acc, m);
+    worker_round<WK, 40, HAS_T>(lane, acc, m);
+    worker_round<WK, 48, HAS_T>(lane, acc, m);
+    worker_round<WK, 56, HAS_T>(lane, acc, m);
+}
+
+template <bool HAS_T>
+__device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, double* smem)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fk = lane >> 4;
     const int K0 = j * kNB;
     const int R0 = R * kNB;
     const int n_blk = a.n_blk, ld = a.ld, n_pad = a.n_pad;
     const unsigned epoch = *a.epoch_word + 1u;
-    double* RA = smem;                       // D-only role: L^T (stride kLdT); others: result tile (stride kLd)
-    double* Pd = RA + 64 * kLdT;
-    double* Pt = Pd + 2 * 64 * kPs;
-    double* invd = Pt + 2 * 64 * kPs;
-    double* Xs = invd + 64;                  // [2 buffers][J | R][8][kLdsRow]
-    double* Li = Xs + 4 * kDfXs;             // diagonal factor, row stride kLd (inverse)
+    Lds m;
+    m.RA = smem;
+    m.Pd = m.RA + 64 * kLdT;
+    m.Pt = m.Pd + 2 * 64 * kPs;
+    m.invd = m.Pt + 2 * 64 * kPs;
+    m.Xs = m.invd + 64;
+    m.stamp_j = -1;
+#ifdef VMM_STAMPS
+    if (HAS_T && R == j + 1)
+        m.stamp_j = j;
+    {
+        const bool stamp_on = m.stamp_j >= 0 && w == 0;
+        const int stamp_j = m.stamp_j;
+        DF_RT(0);
+    }
+#endif
+    double* Li = m.Xs + 4 * kDfXs;           // diagonal factor, row stride kLd (inverse)
     double* di = Li + 64 * kLd;
     __shared__ int s_timeout;
     if (tid == 0)
         s_timeout = 0;
-    const double* __restrict__ S = a.S;
-    double4_t Dacc[4], Tacc[4];
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-        Dacc[tj] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-        Tacc[tj] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * w + fk + 4 * r;
-            const double dv = S[(int64_t)(K0 + row) * ld + K0 + 16 * tj + fr];
-            Dacc[tj][r] = (tj <= w) ? dv : 0.0;
-            if (HAS_T) {
-                const int grow = (R0 + row <= n_pad) ? R0 + row : n_pad;   // clamp: always in bounds
-                const double tv = S[(int64_t)grow * ld + K0 + 16 * tj + fr];
-                Tacc[tj][r] = (R0 + row <= n_pad) ? tv : 0.0;
-            }
-        }
-    }
-    // slices of panel k: row blocks k+1 .. n_blk, eight rounds each
-    auto slice = [&](int k, int rb, int r) -> unsigned long long* {
-        const int64_t base = (int64_t)k * n_blk - (int64_t)k * (k - 1) / 2 + (rb - k - 1);
-        return a.G + (base * 8 + r) * kDfSlice;
-    };
-    // 1. the panels before mine, eight columns per step, as they are published
-    const int n_it = 8 * j;
+    SliceMap sm;
+    sm.G = a.G;
+    sm.n_blk = n_blk;
     __syncthreads();   // s_timeout
-    if (n_it > 0) {
-        DfQuarter qJ, qR;
-        df_issue(slice(0, j, 0), w, lane, qJ);
-        if (HAS_T)
-            df_issue(slice(0, R, 0), w, lane, qR);
-        else
-            qR = qJ;
-        for (int it = 0; it < n_it; ++it) {
-            const int k = it >> 3, r = it & 7;
-            const unsigned long long* sJ = slice(k, j, r);
-            const unsigned long long* sR = HAS_T ? slice(k, R, r) : sJ;
-            const bool got = df_wait<HAS_T>(sJ, sR, w, lane, epoch, a.abort_word, qJ, qR);
-            double* XJ = Xs + (it & 1) * 2 * kDfXs;
-            double* XR = XJ + kDfXs;
-            const double nan = __longlong_as_double(0x7ff8000000000000ll);
-            XJ[(2 * w) * kLdsRow + lane] = got ? df_value(qJ.a0, qJ.a1) : nan;
-            XJ[(2 * w + 1) * kLdsRow + lane] = got ? df_value(qJ.b0, qJ.b1) : nan;
-            if (HAS_T) {
-                XR[(2 * w) * kLdsRow + lane] = got ? df_value(qR.a0, qR.a1) : nan;
-                XR[(2 * w + 1) * kLdsRow + lane] = got ? df_value(qR.b0, qR.b1) : nan;
-            }
-            if (!got && lane == 0) {
-                s_timeout = 1;
-                __hip_atomic_store(a.abort_word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            if (it + 1 < n_it) {   // the next slice is requested before this one is applied
-                const int k2 = (it + 1) >> 3, r2 = (it + 1) & 7;
-                df_issue(slice(k2, j, r2), w, lane, qJ);
-                if (HAS_T)
-                    df_issue(slice(k2, R, r2), w, lane, qR);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int row = (ks * 4 + fk) * kLdsRow;
-                const double ad = -XJ[row + 16 * w + fr];
-                const double at = HAS_T ? -XR[row + 16 * w + fr] : 0.0;
-#pragma unroll
-                for (int tj = 0; tj < 4; ++tj) {
-                    const double b = XJ[row + 16 * tj + fr];
-                    const double adm = (tj <= w) ? ad : 0.0;
-                    Dacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(adm, b, Dacc[tj], 0, 0, 0);
-                    if (HAS_T)
-                        Tacc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(at, b, Tacc[tj], 0, 0, 0);
-                }
-            }
-        }
-    }
-    // 2. my own panel; the rows below leave round by round
     bool ok = true;
-    unsigned long long* g0 = HAS_T ? slice(j, R, 0) : nullptr;
-    panel_round<0, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, g0, epoch);
-    panel_round<8, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 1 * kDfSlice : nullptr, epoch);
-    panel_round<16, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 2 * kDfSlice : nullptr, epoch);
-    panel_round<24, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 3 * kDfSlice : nullptr, epoch);
-    panel_round<32, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 4 * kDfSlice : nullptr, epoch);
-    panel_round<40, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 5 * kDfSlice : nullptr, epoch);
-    panel_round<48, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 6 * kDfSlice : nullptr, epoch);
-    panel_round<56, HAS_T>(w, lane, Dacc, Tacc, Pd, Pt, RA, RA, invd, ok, HAS_T ? g0 + 7 * kDfSlice : nullptr, epoch);
-    __syncthreads();
-    // 3. results for the kernels after this launch
+    if (w < 2)
+        pivot_path<HAS_T>(a, w, lane, j, R, m, sm, epoch, &s_timeout, ok);
+    else if (w == 2)
+        worker_path<0, HAS_T>(a, lane, j, R, m);
+    else
+        worker_path<1, HAS_T>(a, lane, j, R, m);
+    // results for the kernels after this launch (the last barrier of the last round orders the LDS tiles)
     if (!HAS_T) {
         if (tid < 64)
-            a.dinv[K0 + tid] = invd[tid];
+            a.dinv[K0 + tid] = m.invd[tid];
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int r = idx >> 6, c = idx & 63;
-            const double v = (c <= r) ? RA[c * kLdT + r] : 0.0;
+            const double v = (c <= r) ? m.RA[c * kLdT + r] : 0.0;
             if (c <= r)
                 a.Ld[(int64_t)j * 4096 + r * 64 + c] = v;
             Li[r * kLd + c] = v;
         }
         if (tid < 64)
-            di[tid] = invd[tid];
+            di[tid] = m.invd[tid];
         __syncthreads();
         if (j < n_blk - 1)   // the chain solves the last block directly
             chol_inverse_lds(Li, di, a.Linv + (int64_t)j * 4096);
@@ -1076,10 +1428,8 @@ __device__ __forceinline__ void df_role(const DfArgs& a, const int j, const int 
         const int rr = idx >> 5, c = (idx & 31) * 2;
         if (R0 + rr <= n_pad)
             *reinterpret_cast<double2*>(a.S + (int64_t)(R0 + rr) * ld + K0 + c)
-                = make_double2(RA[rr * kLd + c], RA[rr * kLd + c + 1]);
+                = make_double2(m.RA[rr * kLd + c], m.RA[rr * kLd + c + 1]);
     }
-    // the last panel's row block (the rhs row) closes the factorisation: a failed pivot anywhere has reached it
-    // as NaN through the published columns; a timeout anywhere through the abort word
     if (j == n_blk - 1 && tid == 0) {
         const bool aborted = __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
         if (!ok || s_timeout || aborted)
@@ -1087,12 +1437,16 @@ __device__ __forceinline__ void df_role(const DfArgs& a, const int j, const int 
     }
 }
 
+} // namespace df2
+
 __global__ __launch_bounds__(256) void k_chol_dataflow(const DfArgs a)
 {
-    if (a.ctl->done || a.ctl->lin_fail)
+    if (a.ctl->done)
+        return;
+    phase_stamp(a.ctl, 3);
+    if (a.ctl->lin_fail)
         return;
     __shared__ __attribute__((aligned(16))) double smem[kDfSmem];
-    // blockIdx -> (block column j, role): the row blocks j+1 .. n_blk first, the diagonal-only role last
     int b = (int)blockIdx.x, j = 0;
     for (; j < a.n_blk; ++j) {
         const int cnt = a.n_blk - j + 1;
@@ -1103,9 +1457,9 @@ __global__ __launch_bounds__(256) void k_chol_dataflow(const DfArgs a)
     if (j >= a.n_blk)
         return;
     if (b < a.n_blk - j)
-        df_role<true>(a, j, j + 1 + b, smem);
+        df2::role<true>(a, j, j + 1 + b, smem);
     else
-        df_role<false>(a, j, j, smem);
+        df2::role<false>(a, j, j, smem);
 }
 
 // One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their
@@ -1118,7 +1472,11 @@ __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restric
                                                    double* __restrict__ Ld, double* __restrict__ Linv, int n_upd,
                                                    int n_upd_wg)
 {
-    if (ctl->done || ctl->lin_fail)
+    if (ctl->done)
+        return;
+    if (k == 0)
+        phase_stamp(ctl, 3);
+    if (ctl->lin_fail)
         return;
     __shared__ __attribute__((aligned(16))) double smem[kStepSmem];
     if ((int)blockIdx.x < n_panel)
@@ -1208,6 +1566,20 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
             hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y,
                                e.dinv, (const double*)e.Ldiag);
     }
+}
+
+// Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources
+// are known before any launch is recorded into a hipGraph (nothing may be loaded lazily under stream capture).
+int preload_chol_kernels()
+{
+    hipFuncAttributes at;
+    int bad = 0;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsolve_step)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsolve_chain)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_step)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_inverse)) != hipSuccess;
+    return bad;
 }
 
 } // namespace vmm

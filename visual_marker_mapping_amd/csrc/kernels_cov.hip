@@ -263,4 +263,19 @@ void launch_cov_gram(Engine& e, const double* X, int ldb, double* cov_dev)
                        (const double*)e.Le, (const int32_t*)(e.active + e.n_cams), cov_dev);
 }
 
+// Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources
+// are known before any launch is recorded into a hipGraph (nothing may be loaded lazily under stream capture).
+int preload_cov_kernels()
+{
+    hipFuncAttributes at;
+    int bad = 0;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cov_prepare)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cov_identity)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cov_transpose)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_trsm_diag)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_trsm_update)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cov_gram)) != hipSuccess;
+    return bad;
+}
+
 } // namespace vmm

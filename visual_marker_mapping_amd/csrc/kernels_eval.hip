@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
             return;
         if (a.guard_need_jacobian && !a.ctl->need_jacobian)
             return;
+        if (WRITE_W)
+            phase_stamp(a.ctl, 0);
     }
     eval_body<OWN_IS_CAM, WRITE_W, AT>(a, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
 }
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             return;
         if (aE.guard_need_jacobian && !aE.ctl->need_jacobian)
             return;
+        phase_stamp(aE.ctl, 0);
     }
     if ((int)blockIdx.x < nb_e)
         eval_body<E_IS_CAM, true, AT>(aE, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -599,6 +602,35 @@ void launch_project(hipStream_t st, const Intrinsics& K, int64_t n, const double
 {
     if (n > 0)
         hipLaunchKernelGGL(k_project, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, K, n, pc, uv);
+}
+
+// Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources
+// are known before any launch is recorded into a hipGraph (nothing may be loaded lazily under stream capture).
+int preload_eval_kernels()
+{
+    hipFuncAttributes at;
+    int bad = 0;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, true, double>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, true, double>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, false, double>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, false, double>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, true, float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, true, float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, false, float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, false, float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<true, double>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, double>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<true, float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_pose)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_sum)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cost<true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cost<false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_stats<true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_stats<false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_stats_pose)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_project)) != hipSuccess;
+    return bad;
 }
 
 } // namespace vmm

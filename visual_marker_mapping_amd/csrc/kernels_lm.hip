@@ -114,6 +114,7 @@ __global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, c
 {
     if (ctl->done)
         return;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     __shared__ double sh[256];
     __shared__ int s_stop, s_reuse, s_evaluated;
     __shared__ double s_radius, s_lo, s_hi, s_xn, s_gm, s_cst;
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, c
     if (tid == 0) {
         // one load and one store of the control block: field-by-field global accesses cost ~0.5 us each
         LmCtl c = *ctl;
+        c.stamp[1] = t_begin;
         if (s_evaluated) {
+            c.phase_ticks[0] += t_begin > c.stamp[0] ? t_begin - c.stamp[0] : 0ull;
             const double cst = s_cst;
             const bool first = c.first_eval != 0;
             c.x_cost = cst;
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
 {
     if (ctl->done)
         return;
+    phase_stamp(ctl, 4);
     const int e = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (e >= n_e)
@@ -395,6 +399,7 @@ __global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const 
 {
     if (ctl->done)
         return;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     __shared__ double sh[256];
     __shared__ int s_accept;
     const int tid = threadIdx.x;
@@ -492,6 +497,14 @@ __global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const 
                 }
             }
         }
+        {
+            // phase report: the groups of this iteration (stamps of a skipped group are older than its predecessor's)
+            auto span = [](unsigned long long a, unsigned long long b) { return b > a ? b - a : 0ull; };
+            c.phase_ticks[2] += span(c.stamp[2], c.stamp[3]);
+            c.phase_ticks[3] += span(c.stamp[3], c.stamp[4]);
+            c.phase_ticks[4] += span(c.stamp[4], t_begin);
+            c.phase_ticks[1] += span(c.stamp[1], c.stamp[2]) + span(t_begin, __builtin_amdgcn_s_memrealtime());
+        }
         *ctl = c;
         s_accept = accept;
     }
@@ -564,6 +577,20 @@ void launch_decide(Engine& e)
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), e.pose_part,
                        e.step_comm + 6 * (size_t)e.n_e, single ? e.part_cross : (const double*)nullptr, e.n_e,
                        e.cost_comm, single ? e.part_k1 : (const double*)nullptr, e.ordE.n_tasks);
+}
+
+// Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources
+// are known before any launch is recorded into a hipGraph (nothing may be loaded lazily under stream capture).
+int preload_lm_kernels()
+{
+    hipFuncAttributes at;
+    int bad = 0;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_iter_begin)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_candidate)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_decide)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_zero_unless_eval)) != hipSuccess;
+    return bad;
 }
 
 } // namespace vmm

@@ -53,6 +53,7 @@ __global__ void k_elim_factor(LmCtl* ctl, int n_e, int e_off_pose, const double*
 {
     if (ctl->done)
         return;
+    phase_stamp(ctl, 2);
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_e)
         return;
@@ -471,6 +472,23 @@ void launch_add_diag(Engine& e)
     const int threads = 36 * e.n_f + (e.n_pad - e.n_red);
     hipLaunchKernelGGL(k_add_diag, dim3((threads + 255) / 256), dim3(256), 0, e.stream, e.ctl, e.n_f, f_off, H_F, g_F,
                        e.scale, e.D2, e.S, e.ldz, e.n_red, e.n_pad);
+}
+
+// Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources
+// are known before any launch is recorded into a hipGraph (nothing may be loaded lazily under stream capture).
+int preload_schur_kernels()
+{
+    hipFuncAttributes at;
+    int bad = 0;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_elim_factor)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<double>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_syrk_streamk)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_add_diag)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_pack_lower)) != hipSuccess;
+    return bad;
 }
 
 } // namespace vmm

@@ -4,7 +4,9 @@
 // (/root/reference/src/TagReconstructor.cpp:646-743): vmm_ba_create() takes the place of the
 // ceres::Problem construction (:657-724), vmm_ba_solve() of ceres::Solve (:737-738).  No CPU
 // fallback exists: without a HIP device every entry point fails with VMM_BA_ERR_HIP.
+#include <dlfcn.h>
 #include <math.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl.so is resolved with dlopen when a communicator is asked for
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,6 +54,72 @@ static int upload(Engine& e, T* dst, const std::vector<T>& src)
 }
 
 static int round_up(int64_t v, int m) { return (int)(((v + m - 1) / m) * m); }
+
+// ---- optional libraries, resolved at run time (libvmm_ba.so itself links only the HIP runtime) ----
+// roctx ranges around the solve and its iterations (rocprofv3 --marker-trace / the reference prints
+// summary.FullReport(), src/TagReconstructor.cpp:741-742; the numeric phase report is in vmm_ba_summary).
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h)
+            h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        }
+    }
+};
+static Roctx& roctx()
+{
+    static Roctx r;
+    return r;
+}
+struct Range {
+    explicit Range(const char* name)
+    {
+        if (roctx().push)
+            roctx().push(name);
+    }
+    ~Range()
+    {
+        if (roctx().pop)
+            roctx().pop();
+    }
+};
+
+// RCCL (north_star: "RCCL all-reduce over xGMI of the reduced camera system")
+struct Rccl {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+    Rccl()
+    {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h)
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h)
+            h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h)
+            return;
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(h, "ncclAllReduce"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        ok = GetUniqueId && CommInitRank && AllReduce && CommDestroy && GetErrorString;
+    }
+};
+static Rccl& rccl()
+{
+    static Rccl r;
+    return r;
+}
 
 // Sorts the observations by one pose family (stable counting sort) and cuts each pose's run into
 // wave-sized tasks.
@@ -111,8 +179,10 @@ static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx
 
 // Work plan of the rank-k update: lower 128x128 tiles with row blocks 0..n_row_blk-1 and column blocks
 // 0..n_col_blk-1 (bj <= bi), K stages of 16 rows; the unit of work is one K stage of one tile.
-//   * Fewer tiles than workgroup slots (500 x 200: 55 tiles, 512 slots): "stream-K" -- all units, tile-major,
-//     are cut into equal contiguous ranges, one per workgroup.
+//   * At most slots / 8 tiles (500 x 200: 55 tiles, 512 slots): one K slice per XCD -- workgroup b takes the
+//     (b % 8)-th eighth of K of tile b / 8 (see below).
+//   * Otherwise fewer tiles than workgroup slots: "stream-K" -- all units, tile-major, are cut into equal contiguous
+//     ranges, one per workgroup.
 //   * More tiles than slots (2000 x 1000: 1128 tiles): whole rounds of one-tile-per-workgroup first, XCD-aware:
 //     workgroup b runs on XCD b % 8, so the 64 workgroups an XCD holds at a time get 64 CONSECUTIVE tiles of
 //     the row-major tile list -- one or two block rows -- and sweep K in step: the A panel of a block row and
@@ -144,6 +214,43 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
     const int64_t slots = per_cu * (int64_t)hw;
     const bool xcd_rounds = !(getenv("VMM_BA_SYRK_NO_XCD") && getenv("VMM_BA_SYRK_NO_XCD")[0] == '1');
     const int n_xcd = 8;
+    std::vector<int64_t> wg_u0, wg_u1;
+    std::vector<int32_t> wg_seg0, tile_seg0((size_t)p.n_tiles + 1, 0);
+    int seg = 0;
+    if (xcd_rounds && (int64_t)p.n_tiles * n_xcd <= slots && p.n_kt >= n_xcd) {
+        // Few tiles (500 x 200: 55): one K slice per XCD.  Workgroup b runs on XCD b % 8 (round-robin dispatch)
+        // and owns the (b % 8)-th eighth of K of tile b / 8, so the 55 workgroups of an XCD sweep the SAME rows of
+        // Z in step: every row is fetched into that XCD's L2 once and shared (Z crosses the fabric once per launch
+        // instead of once per workgroup), and every tile leaves exactly eight partials.  Off-diagonal tiles come
+        // first in the tile list: the second workgroup a CU receives is then one of the cheaper diagonal tiles.
+        std::vector<int> order;
+        for (int t = 0; t < p.n_tiles; ++t)
+            if (bi[t] != bj[t])
+                order.push_back(t);
+        for (int t = 0; t < p.n_tiles; ++t)
+            if (bi[t] == bj[t])
+                order.push_back(t);
+        std::vector<int32_t> bi2(bi.size()), bj2(bj.size());
+        for (int t = 0; t < p.n_tiles; ++t) {
+            bi2[t] = bi[order[t]];
+            bj2[t] = bj[order[t]];
+        }
+        bi.swap(bi2);
+        bj.swap(bj2);
+        p.n_wg = p.n_tiles * n_xcd;
+        wg_u0.resize((size_t)p.n_wg);
+        wg_u1.resize((size_t)p.n_wg);
+        wg_seg0.resize((size_t)p.n_wg);
+        for (int b = 0; b < p.n_wg; ++b) {
+            const int x = b % n_xcd, t = b / n_xcd;
+            wg_u0[b] = (int64_t)t * p.n_kt + (int64_t)p.n_kt * x / n_xcd;
+            wg_u1[b] = (int64_t)t * p.n_kt + (int64_t)p.n_kt * (x + 1) / n_xcd;
+            wg_seg0[b] = n_xcd * t + x;
+        }
+        for (int t = 0; t <= p.n_tiles; ++t)
+            tile_seg0[t] = n_xcd * t;
+        seg = n_xcd * p.n_tiles;
+    } else {
     const int64_t full_rounds = (xcd_rounds && slots % n_xcd == 0) ? p.n_tiles / slots : 0;
     const int64_t tiles_a = full_rounds * slots;                      // one tile per workgroup
     const int64_t units_b = (int64_t)(p.n_tiles - tiles_a) * p.n_kt;  // the rest: stream-K
@@ -159,8 +266,7 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
         lu0[(size_t)l] = l * p.n_kt;
     for (int64_t l = 0; l <= n_wg_b; ++l)
         lu0[(size_t)(tiles_a + l)] = std::min<int64_t>(tiles_a * p.n_kt + l * upw_b, (int64_t)p.n_tiles * p.n_kt);
-    std::vector<int32_t> lseg0((size_t)p.n_wg + 1, 0), tile_seg0((size_t)p.n_tiles + 1, 0);
-    int seg = 0;
+    std::vector<int32_t> lseg0((size_t)p.n_wg + 1, 0);
     for (int l = 0; l < p.n_wg; ++l) {
         lseg0[l] = seg;
         int64_t u = lu0[l];
@@ -176,10 +282,10 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
         }
     }
     tile_seg0[p.n_tiles] = seg;
-    p.n_segments = seg;
     // blockIdx -> logical workgroup: inside a full round, XCD x (blockIdx % 8) takes the x-th run of slots/8 tiles
-    std::vector<int64_t> wg_u0((size_t)p.n_wg), wg_u1((size_t)p.n_wg);
-    std::vector<int32_t> wg_seg0((size_t)p.n_wg);
+    wg_u0.resize((size_t)p.n_wg);
+    wg_u1.resize((size_t)p.n_wg);
+    wg_seg0.resize((size_t)p.n_wg);
     for (int b = 0; b < p.n_wg; ++b) {
         int64_t l = b;
         if (b < tiles_a) {
@@ -190,6 +296,8 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
         wg_u1[b] = lu0[(size_t)l + 1];
         wg_seg0[b] = lseg0[(size_t)l];
     }
+    }
+    p.n_segments = seg;
     int rc;
     if ((rc = dev_alloc(e, &p.tile_bi, bi.size()))) return rc;
     if ((rc = dev_alloc(e, &p.tile_bj, bj.size()))) return rc;
@@ -221,6 +329,16 @@ static int do_allreduce(Engine& e, double* buf, size_t count)
 {
     if (!e.multi)
         return VMM_BA_OK;
+    if (e.rccl_comm) {
+        // in place, on the engine's stream: ordered behind the kernels that filled the buffer, capturable
+        const ncclResult_t r = rccl().AllReduce(buf, buf, count, ncclDouble, ncclSum,
+                                                reinterpret_cast<ncclComm_t>(e.rccl_comm), e.stream);
+        if (r != ncclSuccess) {
+            set_error(std::string("ncclAllReduce: ") + rccl().GetErrorString(r));
+            return VMM_BA_ERR_COLLECTIVE;
+        }
+        return VMM_BA_OK;
+    }
     if (!e.allreduce) {
         set_error("world_size > 1 but no all-reduce callback was set (vmm_ba_set_allreduce)");
         return VMM_BA_ERR_STATE;
@@ -244,6 +362,8 @@ static void destroy_engine(Engine* e)
     for (auto& g : e->iter_graph_seg)
         if (g)
             (void)hipGraphExecDestroy(g);
+    if (e->rccl_comm)
+        (void)rccl().CommDestroy(reinterpret_cast<ncclComm_t>(e->rccl_comm));
     for (void* p : e->allocs)
         (void)hipFree(p);
     if (e->ctl_host)
@@ -304,8 +424,11 @@ static int allreduce_after(Engine& e, int seg)
 
 static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
 {
+    static const char* const names[5] = { "vmm_ba evaluation", "vmm_ba eliminate + rank-k", "vmm_ba factor + solve",
+                                          "vmm_ba candidate + cost", "vmm_ba decide" };
     int rc;
     for (int seg = 0; seg < 5; ++seg) {
+        Range r(names[seg]);
         enqueue_segment(e, o, seg);
         if (e.multi && (rc = allreduce_after(e, seg)))
             return rc;
@@ -314,14 +437,30 @@ static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
     return VMM_BA_OK;
 }
 
-static int capture_graph(Engine& e, hipGraphExec_t* out, const std::function<void()>& body)
+// Records `body` (kernel launches, and ncclAllReduce calls when a communicator is attached) into a hipGraph.
+// Nothing may fail silently here: a sticky error from before the capture, or a call that invalidates the capture,
+// is reported with the place where it was noticed (`where` is set by the body after every group).
+static int capture_graph(Engine& e, hipGraphExec_t* out, const std::function<int(const char**)>& body)
 {
+    const hipError_t pre = hipGetLastError();
+    if (pre != hipSuccess) {
+        set_error(std::string("error pending before hipStreamBeginCapture: ") + hipGetErrorString(pre));
+        return VMM_BA_ERR_HIP;
+    }
     hipGraph_t g = nullptr;
     HIP_TRY(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-    body();
+    const char* where = "start";
+    const int rc = body(&where);
     const hipError_t ee = hipStreamEndCapture(e.stream, &g);
+    if (rc != VMM_BA_OK) {
+        if (g)
+            (void)hipGraphDestroy(g);
+        return rc;
+    }
     if (ee != hipSuccess || !g) {
-        set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+        set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(ee) + " (capture invalidated at or before: " + where
+                  + ")");
+        (void)hipGetLastError();
         return VMM_BA_ERR_HIP;
     }
     const hipError_t ei = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
@@ -332,6 +471,15 @@ static int capture_graph(Engine& e, hipGraphExec_t* out, const std::function<voi
         return VMM_BA_ERR_HIP;
     }
     return VMM_BA_OK;
+}
+
+// after a group of launches under capture: is the capture still alive?
+static bool capture_alive(Engine& e)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(e.stream, &st) != hipSuccess)
+        return false;
+    return st == hipStreamCaptureStatusActive;
 }
 
 static void drop_graphs(Engine& e)
@@ -347,39 +495,66 @@ static void drop_graphs(Engine& e)
     }
 }
 
-// The iteration is captured once into hipGraphs and replayed (about 35 small launches; eager enqueueing is
-// host-bound).  One GPU: one graph.  World > 1: the all-reduce callbacks are host calls, so the five kernel
-// groups between them are five graphs launched around the callbacks.
+static const char* const kSegName[5] = { "evaluation", "control + eliminate + rank-k update", "factor + solve + back-substitution",
+                                         "candidate + cost", "decide" };
+
+// The iteration is captured once into hipGraphs and replayed (eager enqueueing is host-bound).
+//   one GPU:                      one graph;
+//   world > 1, RCCL communicator: one graph, the four ncclAllReduce calls recorded between the kernel groups
+//                                 (VMM_BA_RCCL_GRAPH=0: five graphs with the collectives enqueued between them);
+//   world > 1, host callback:     the callbacks are host calls, so the five kernel groups between them are five graphs.
+// No kernel is launched for the first time under capture: vmm_ba_create touches every kernel (preload_*_kernels).
+// Round 1 ran the first iteration of a handle eagerly because of an intermittent "operation failed due to a previous
+// error during capture" at 2000 x 1000; VMM_BA_EAGER_FIRST=1 brings that back.
 static int run_iteration(Engine& e, const vmm_ba_options& o)
 {
     if (!e.use_graph)
         return enqueue_iteration(e, o);
-    if (!e.launched_eagerly) {
-        // the first iteration of a handle runs eagerly: first launches may load code objects or size
-        // per-kernel resources, which is not allowed inside a stream capture (seen as an intermittent
-        // "operation failed due to a previous error during capture" on the 2000 x 1000 problem)
+    if (e.eager_first && !e.launched_eagerly) {
         e.launched_eagerly = true;
         return enqueue_iteration(e, o);
     }
-    const bool have = e.multi ? e.iter_graph_seg[0] != nullptr : e.iter_graph != nullptr;
+    const bool one_graph = !e.multi || (e.rccl_comm && e.rccl_graph);
+    const bool have = one_graph ? e.iter_graph != nullptr : e.iter_graph_seg[0] != nullptr;
     if (!have || e.graph_robustify != o.robustify || e.graph_huber_a != o.huber_a) {
         drop_graphs(e);
         int rc;
-        if (e.multi) {
+        if (one_graph) {
+            rc = capture_graph(e, &e.iter_graph, [&](const char** where) -> int {
+                for (int seg = 0; seg < 5; ++seg) {
+                    enqueue_segment(e, o, seg);
+                    int r;
+                    if (e.multi && (r = allreduce_after(e, seg)))
+                        return r;
+                    if (capture_alive(e))
+                        *where = kSegName[seg];
+                }
+                return VMM_BA_OK;
+            });
+            if (rc && e.multi && e.rccl_comm) {
+                // a collective that cannot be recorded: fall back to graphs around eagerly enqueued collectives
+                e.rccl_graph = false;
+                return run_iteration(e, o);
+            }
+            if (rc)
+                return rc;
+        } else {
             for (int seg = 0; seg < 5; ++seg)
-                if ((rc = capture_graph(e, &e.iter_graph_seg[seg], [&] { enqueue_segment(e, o, seg); }))) {
+                if ((rc = capture_graph(e, &e.iter_graph_seg[seg], [&](const char** where) -> int {
+                         enqueue_segment(e, o, seg);
+                         if (capture_alive(e))
+                             *where = kSegName[seg];
+                         return VMM_BA_OK;
+                     }))) {
                     drop_graphs(e);
                     return rc;
                 }
-        } else if ((rc = capture_graph(e, &e.iter_graph, [&] {
-                       for (int seg = 0; seg < 5; ++seg)
-                           enqueue_segment(e, o, seg);
-                   })))
-            return rc;
+        }
         e.graph_robustify = o.robustify;
         e.graph_huber_a = o.huber_a;
     }
-    if (!e.multi) {
+    Range r("vmm_ba lm_iteration");
+    if (one_graph) {
         HIP_TRY(hipGraphLaunch(e.iter_graph, e.stream));
         return VMM_BA_OK;
     }
@@ -529,6 +704,21 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         if (fw[0] == '1')
             e.multi = true;   // test hook: one rank, but staging buffers + eager launches + all-reduce callbacks
     {
+        // every kernel is touched once per process and device before anything is captured
+        static bool preloaded[64] = {};
+        if (e.device < 64 && !preloaded[e.device]) {
+            const int bad = preload_eval_kernels() + preload_schur_kernels() + preload_chol_kernels() + preload_lm_kernels()
+                + preload_cov_kernels();
+            if (bad) {
+                set_error("hipFuncGetAttributes failed for " + std::to_string(bad) + " kernels (code object not loadable on this device)");
+                return fail(VMM_BA_ERR_HIP);
+            }
+            preloaded[e.device] = true;
+        }
+        const char* ef = getenv("VMM_BA_EAGER_FIRST");
+        e.eager_first = ef && ef[0] == '1';
+        const char* rg = getenv("VMM_BA_RCCL_GRAPH");
+        e.rccl_graph = !(rg && rg[0] == '0');
         const char* ng = getenv("VMM_BA_NO_GRAPH");
         e.use_graph = !(ng && ng[0] == '1');
         const char* nc = getenv("VMM_BA_NO_CHAIN");
@@ -677,6 +867,60 @@ int vmm_ba_set_allreduce(vmm_ba_handle h, vmm_ba_allreduce_fn fn, void* user)
     return VMM_BA_OK;
 }
 
+int vmm_ba_rccl_unique_id(void* id128)
+{
+    if (!id128) {
+        set_error("null argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    if (!rccl().ok) {
+        set_error("librccl.so could not be loaded");
+        return VMM_BA_ERR_COLLECTIVE;
+    }
+    static_assert(sizeof(ncclUniqueId) == VMM_BA_RCCL_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    const ncclResult_t r = rccl().GetUniqueId(&id);
+    if (r != ncclSuccess) {
+        set_error(std::string("ncclGetUniqueId: ") + rccl().GetErrorString(r));
+        return VMM_BA_ERR_COLLECTIVE;
+    }
+    memcpy(id128, &id, sizeof(id));
+    return VMM_BA_OK;
+}
+
+int vmm_ba_enable_rccl(vmm_ba_handle h, const void* id128)
+{
+    if (!h || !id128) {
+        set_error("null argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!e.multi) {
+        set_error("vmm_ba_enable_rccl: the handle was created with world_size 1");
+        return VMM_BA_ERR_STATE;
+    }
+    if (!rccl().ok) {
+        set_error("librccl.so could not be loaded");
+        return VMM_BA_ERR_COLLECTIVE;
+    }
+    HIP_TRY(hipSetDevice(e.device));
+    if (e.rccl_comm) {
+        (void)rccl().CommDestroy(reinterpret_cast<ncclComm_t>(e.rccl_comm));
+        e.rccl_comm = nullptr;
+    }
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = rccl().CommInitRank(&comm, e.world, id, e.rank);
+    if (r != ncclSuccess) {
+        set_error(std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+        return VMM_BA_ERR_COLLECTIVE;
+    }
+    e.rccl_comm = comm;
+    drop_graphs(e);
+    return VMM_BA_OK;
+}
+
 int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt)
 {
     if (!h) {
@@ -726,6 +970,7 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
         return VMM_BA_ERR_ARGUMENT;
     }
     HIP_TRY(hipSetDevice(e.device));
+    Range solve_range("vmm_ba_solve");
     const auto t0 = std::chrono::steady_clock::now();
     vmm_ba_iteration* user_trace = s->trace;
     const int user_cap = s->trace ? s->trace_capacity : 0;
@@ -778,6 +1023,11 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
     s->elimination = e.elim_cams ? VMM_BA_ELIM_CAMERAS : VMM_BA_ELIM_TAGS;
     s->initial_cost = c.initial_cost;
     s->final_cost = c.x_cost;
+    s->time_eval_s = 1e-8 * (double)c.phase_ticks[0];          // 100 MHz ticks
+    s->time_control_s = 1e-8 * (double)c.phase_ticks[1];
+    s->time_eliminate_s = 1e-8 * (double)c.phase_ticks[2];
+    s->time_factor_solve_s = 1e-8 * (double)c.phase_ticks[3];
+    s->time_step_s = 1e-8 * (double)c.phase_ticks[4];
     if (user_trace && user_cap > 0) {
         const int n = std::min(c.records, user_cap);
         if (n > 0) {

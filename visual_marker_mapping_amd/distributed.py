@@ -76,3 +76,16 @@ def make_allreduce(device_index, group=None):
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
                 t.copy_(h)
     return fn
+
+
+def enable_native_rccl(ba, rank, group=None):
+    """Attaches an RCCL communicator to the handle (BundleAdjuster.enable_rccl): rank 0 draws the id, the process
+    group that launched the ranks (torch.distributed, any backend) carries its 128 bytes to the others.  From then
+    on the library issues ncclAllReduce itself, inside the iteration's hipGraph: no host callback per collective."""
+    import torch
+    import torch.distributed as dist
+    from . import engine as eng
+
+    payload = [eng.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(payload, src=0, group=group)
+    ba.enable_rccl(payload[0])

@@ -107,6 +107,15 @@ class BundleAdjuster:
         self._allreduce_cb = _lib.ALLREDUCE_FN(tramp)
         _lib.check(_lib.lib().vmm_ba_set_allreduce(self._h, self._allreduce_cb, None))
 
+    def enable_rccl(self, unique_id):
+        """Native collective path: ncclAllReduce issued by the library on its own stream, recorded into the LM
+        iteration's hipGraph.  `unique_id` = the 128 bytes rank 0 drew with rccl_unique_id(), identical on every
+        rank; collective call (every rank of the world must make it)."""
+        buf = bytes(unique_id)
+        if len(buf) != _lib.RCCL_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % _lib.RCCL_ID_BYTES)
+        _lib.check(_lib.lib().vmm_ba_enable_rccl(self._h, C.c_char_p(buf)))
+
     # ---- the hot path ----
     def solve(self, options=None, trace_capacity=0, **kw):
         o = options or default_options(**kw)
@@ -160,6 +169,13 @@ class BundleAdjuster:
         t = _lib.KernelTimes()
         _lib.check(_lib.lib().vmm_ba_time_kernels(self._h, C.byref(o), int(reps), C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.KernelTimes._fields_}
+
+
+def rccl_unique_id():
+    """128 bytes identifying a new RCCL communicator (ncclGetUniqueId); drawn on rank 0, handed to every rank."""
+    buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+    _lib.check(_lib.lib().vmm_ba_rccl_unique_id(buf))
+    return buf.raw
 
 
 def project_points(intr, dist, points_cam, device=0):

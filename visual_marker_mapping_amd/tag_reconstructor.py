@@ -498,6 +498,10 @@ class TagReconstructor:
                     it["relative_decrease"], it["trust_region_radius"]))
             print("Cost: initial %.6e final %.6e; iterations %d; time in solver %.4f s" % (
                 summary["initial_cost"], summary["final_cost"], summary["iterations"], summary["time_solve_s"]))
+            print("Time (s): residual + Jacobian evaluation %.6f, elimination + rank-k update %.6f, linear solver %.6f, "
+                  "step + candidate cost %.6f, trust-region control %.6f" % (
+                      summary["time_eval_s"], summary["time_eliminate_s"], summary["time_factor_solve_s"],
+                      summary["time_step_s"], summary["time_control_s"]))
             # covariance report, :761-782 (Eigen prints a row vector with single spaces, 6 significant digits)
             self.lastCovariances = {}
             avg_diag = np.zeros(3)
