@@ -74,6 +74,16 @@ typedef struct vmm_ba_problem {
 #define VMM_BA_PRECISION_F64 0
 #define VMM_BA_PRECISION_F32_ACCUM 1
 
+/* Landmark model.  TAG_POSES: TagReconstructionCostFunction (CostFunction.h:88-184), one 7-parameter pose per tag
+ * -- the live doBundleAdjustment (src/TagReconstructor.cpp:646-743).  POINTS: OpenCVReprojectionError
+ * (CostFunction.h:9-84), four free 3-D points per tag, 3x3 landmark blocks -- doBundleAdjustment_points
+ * (src/TagReconstructor.cpp:457-644, `#if 0` in the reference): the tag poses handed to vmm_ba_create become their
+ * four world corners (:483-491), the origin tag's corners are constant (:494-497), no loss function (:556).
+ * vmm_ba_get_state then returns tag poses rebuilt from the optimised corners (:608-639), vmm_ba_get_points the
+ * corners themselves. */
+#define VMM_BA_LANDMARK_TAG_POSES 0
+#define VMM_BA_LANDMARK_POINTS 1
+
 typedef struct vmm_ba_create_options {
     int32_t device;          /* HIP device ordinal */
     int32_t elimination;     /* VMM_BA_ELIM_* */
@@ -88,6 +98,7 @@ typedef struct vmm_ba_create_options {
      * J^T r, the reduced system S, its factorisation and every LM decision stay f64.  The fixed point
      * (zero gradient) is unchanged, the LM trajectory is that of a slightly perturbed Gauss-Newton model. */
     int32_t precision;
+    int32_t landmarks;       /* VMM_BA_LANDMARK_* */
 } vmm_ba_create_options;
 
 /* Solver::Options fields the reference sets (src/TagReconstructor.cpp:725-735) plus the Ceres
@@ -189,6 +200,10 @@ void vmm_ba_destroy(vmm_ba_handle h);
  * double*, src/TagReconstructor.cpp:665-666,692-693,722). */
 int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt);
 int vmm_ba_get_state(vmm_ba_handle h, double* cam_qt, double* tag_qt);
+
+/* VMM_BA_LANDMARK_POINTS handles: points[12 * n_tags] = the four world corners (LL, LR, UR, UL) of every tag,
+ * the parameter blocks of doBundleAdjustment_points (src/TagReconstructor.cpp:485-492). */
+int vmm_ba_get_points(vmm_ba_handle h, double* points);
 
 int vmm_ba_set_allreduce(vmm_ba_handle h, vmm_ba_allreduce_fn fn, void* user);
 

@@ -22,7 +22,8 @@ class Problem(C.Structure):
                 ("cam_qt", C.POINTER(C.c_double)), ("n_tags", C.c_int),
                 ("tag_qt", C.POINTER(C.c_double)), ("tag_wh", C.POINTER(C.c_double)),
                 ("fixed_tag", C.c_int), ("n_obs", C.c_int), ("obs_cam", C.POINTER(C.c_int)),
-                ("obs_tag", C.POINTER(C.c_int)), ("obs_px", C.POINTER(C.c_double))]
+                ("obs_tag", C.POINTER(C.c_int)), ("obs_px", C.POINTER(C.c_double)),
+                ("landmark_points", C.c_int), ("fixed_tag2", C.c_int)]
 
 
 class Options(C.Structure):
@@ -94,7 +95,9 @@ def default_options(**kw):
 class Scene:
     """Flat problem arrays (owned numpy) + the ctypes view handed to the oracle."""
 
-    def __init__(self, intr, dist, cam_qt, tag_qt, tag_wh, fixed_tag, obs_cam, obs_tag, obs_px):
+    def __init__(self, intr, dist, cam_qt, tag_qt, tag_wh, fixed_tag, obs_cam, obs_tag, obs_px,
+                 landmark_points=False, fixed_tag2=-1):
+        self.landmark_points, self.fixed_tag2 = bool(landmark_points), int(fixed_tag2)
         self.intr = np.ascontiguousarray(intr, np.float64).reshape(4)
         self.dist = np.ascontiguousarray(dist, np.float64).reshape(5)
         self.cam_qt = np.array(cam_qt, np.float64).reshape(-1, 7).copy()
@@ -112,6 +115,7 @@ class Scene:
         p.n_cams, p.cam_qt = len(self.cam_qt), _dp(self.cam_qt)
         p.n_tags, p.tag_qt, p.tag_wh = len(self.tag_qt), _dp(self.tag_qt), _dp(self.tag_wh)
         p.fixed_tag = self.fixed_tag
+        p.landmark_points, p.fixed_tag2 = int(self.landmark_points), self.fixed_tag2
         p.n_obs, p.obs_cam, p.obs_tag, p.obs_px = (len(self.obs_cam), _ip(self.obs_cam),
                                                    _ip(self.obs_tag), _dp(self.obs_px))
         return p
@@ -146,6 +150,52 @@ def obs_eval(intr, dist, cam_qt, tag_qt, wh, px, jac=True):
     lib().vo_obs_eval(_dp(intr), _dp(dist), _dp(cam_qt), _dp(tag_qt), _dp(wh), _dp(px), _dp(r),
                       _dp(Jc) if jac else None, _dp(Jt) if jac else None)
     return (r, Jc, Jt) if jac else r
+
+
+def point_eval(intr, dist, cam_qt, point, uv, jac=True):
+    """OpenCVReprojectionError (TagReconstructionCostFunction.h:21-68): residual (2,), Jc (2,6), Jp (2,3)."""
+    intr, dist = np.ascontiguousarray(intr, np.float64), np.ascontiguousarray(dist, np.float64)
+    cam_qt, point = np.ascontiguousarray(cam_qt, np.float64), np.ascontiguousarray(point, np.float64)
+    uv = np.ascontiguousarray(uv, np.float64)
+    r, Jc, Jp = np.zeros(2), np.zeros((2, 6)), np.zeros((2, 3))
+    lib().vo_point_eval(_dp(intr), _dp(dist), _dp(cam_qt), _dp(point), _dp(uv), _dp(r), _dp(Jc) if jac else None,
+                        _dp(Jp) if jac else None)
+    return (r, Jc, Jp) if jac else r
+
+
+def point_scene(intr, dist, cam_qt, tag_qt, tag_wh, fixed_tag, obs_cam, obs_tag, obs_px):
+    """The point-landmark problem of doBundleAdjustment_points (src/TagReconstructor.cpp:457-644) for the same
+    detections: every tag becomes its four world corners (computeMarkerCorners3D, :483: Eigen rotation, no
+    normalisation), stored as two point pairs; every tag observation becomes two pair observations.
+    Returns (Scene, points) with points (n_tags, 4, 3) the initial corners."""
+    tag_qt = np.asarray(tag_qt, np.float64).reshape(-1, 7)
+    tag_wh = np.asarray(tag_wh, np.float64).reshape(-1, 2)
+    w, x, y, z = tag_qt[:, 0], tag_qt[:, 1], tag_qt[:, 2], tag_qt[:, 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                  2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                  2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+    pts = np.zeros((len(tag_qt), 4, 3))
+    for k, (sx, sy) in enumerate(((-1, -1), (1, -1), (1, 1), (-1, 1))):
+        loc = np.stack([sx * tag_wh[:, 0] / 2, sy * tag_wh[:, 1] / 2, np.zeros(len(tag_wh))], axis=1)
+        pts[:, k] = np.einsum("nij,nj->ni", R, loc) + tag_qt[:, 4:]
+    pair = np.zeros((2 * len(tag_qt), 7))
+    pair[0::2, :6] = pts[:, 0:2].reshape(-1, 6)
+    pair[1::2, :6] = pts[:, 2:4].reshape(-1, 6)
+    obs_cam, obs_tag = np.asarray(obs_cam, np.int32), np.asarray(obs_tag, np.int32)
+    px = np.asarray(obs_px, np.float64).reshape(-1, 8)
+    oc = np.repeat(obs_cam, 2)
+    ot = np.stack([2 * obs_tag, 2 * obs_tag + 1], axis=1).reshape(-1)
+    opx = np.zeros((2 * len(px), 8))
+    opx[0::2, :4] = px[:, :4]
+    opx[1::2, :4] = px[:, 4:]
+    sc = Scene(intr, dist, cam_qt, pair, np.ones((len(pair), 2)), 2 * fixed_tag if fixed_tag >= 0 else -1, oc, ot, opx,
+               landmark_points=True, fixed_tag2=2 * fixed_tag + 1 if fixed_tag >= 0 else -1)
+    return sc, pts
+
+
+def scene_points(scene):
+    """(n_tags, 4, 3) points of a point_scene after a solve."""
+    return scene.tag_qt[:, :6].reshape(-1, 2, 2, 3).reshape(-1, 4, 3)
 
 
 def huber(a, s):

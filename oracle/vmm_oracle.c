@@ -235,6 +235,125 @@ void vo_obs_eval(const double intr[4], const double dist[5], const double cam_qt
     }
 }
 
+/* OpenCVReprojectionError (TagReconstructionCostFunction.h:21-68): ceres::UnitQuaternionRotatePoint -- NO
+ * normalisation of camera_q (:27) -- then the same projection as the tag functor (:38-63).  The Jacobians are what
+ * AutoDiffCostFunction<..., 2, 3, 4, 3> (:74-75) followed by QuaternionParameterization (src/TagReconstructor.cpp:529)
+ * give: d/d(point) = A R_u(q); d/d(delta) = A [dR_u(q)p/dq] G(q) with G the 4x3 Jacobian of Plus at delta = 0
+ * (SURVEY.md Appendix A.2); R_u(q) = I + 2 M(q) is the polynomial UnitQuaternionRotatePoint evaluates, so for a
+ * quaternion that is not exactly unit this is NOT 2 (R p) x g. */
+void vo_point_eval(const double intr[4], const double dist[5], const double cam_qt[7], const double point[3],
+                   const double obs_uv[2], double residual[2], double* Jc, double* Jp)
+{
+    double pc[3], uv[2];
+    unit_quat_rotate(cam_qt, point, pc);        /* :27 */
+    pc[0] += cam_qt[4];                         /* :29-31 */
+    pc[1] += cam_qt[5];
+    pc[2] += cam_qt[6];
+    project_distort(intr, dist, pc, uv);        /* :34-63 */
+    residual[0] = uv[0] - obs_uv[0];            /* :66-67 */
+    residual[1] = uv[1] - obs_uv[1];
+    if (!Jc && !Jp)
+        return;
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = dist[4];
+    const double iz = 1.0 / pc[2];
+    const double x = pc[0] * iz, y = pc[1] * iz;
+    const double r2 = x * x + y * y;
+    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    const double dr = k1 + r2 * (2.0 * k2 + 3.0 * k3 * r2);
+    const double D00 = rad + 2.0 * x * x * dr + 2.0 * p1 * y + 6.0 * p2 * x;
+    const double D01 = 2.0 * x * y * dr + 2.0 * p1 * x + 2.0 * p2 * y;
+    const double D11 = rad + 2.0 * y * y * dr + 2.0 * p2 * x + 6.0 * p1 * y;
+    double G[2][3];
+    G[0][0] = intr[0] * D00 * iz;
+    G[0][1] = intr[0] * D01 * iz;
+    G[0][2] = -intr[0] * (D00 * x + D01 * y) * iz;
+    G[1][0] = intr[1] * D01 * iz;
+    G[1][1] = intr[1] * D11 * iz;
+    G[1][2] = -intr[1] * (D01 * x + D11 * y) * iz;
+    const double qw = cam_qt[0], qx = cam_qt[1], qy = cam_qt[2], qz = cam_qt[3];
+    const double p0 = point[0], p1w = point[1], p2w = point[2];
+    /* R_u(q) = I + 2 M(q) */
+    const double Ru[9] = { 1.0 - 2.0 * (qy * qy + qz * qz), 2.0 * (qx * qy - qw * qz), 2.0 * (qx * qz + qw * qy),
+                           2.0 * (qx * qy + qw * qz), 1.0 - 2.0 * (qx * qx + qz * qz), 2.0 * (qy * qz - qw * qx),
+                           2.0 * (qx * qz - qw * qy), 2.0 * (qy * qz + qw * qx), 1.0 - 2.0 * (qx * qx + qy * qy) };
+    /* columns of d(R_u p)/d(w,x,y,z) */
+    const double Dq[3][4] = {
+        { 2.0 * (qy * p2w - qz * p1w), 2.0 * (qy * p1w + qz * p2w), 2.0 * (-2.0 * qy * p0 + qx * p1w + qw * p2w),
+          2.0 * (-2.0 * qz * p0 - qw * p1w + qx * p2w) },
+        { 2.0 * (qz * p0 - qx * p2w), 2.0 * (qy * p0 - 2.0 * qx * p1w - qw * p2w), 2.0 * (qx * p0 + qz * p2w),
+          2.0 * (qw * p0 - 2.0 * qz * p1w + qy * p2w) },
+        { 2.0 * (qx * p1w - qy * p0), 2.0 * (qz * p0 + qw * p1w - 2.0 * qx * p2w), 2.0 * (-qw * p0 + qz * p1w - 2.0 * qy * p2w),
+          2.0 * (qx * p0 + qy * p1w) } };
+    /* Plus Jacobian at delta = 0 (rows w,x,y,z) */
+    const double Gq[4][3] = { { -qx, -qy, -qz }, { qw, qz, -qy }, { -qz, qw, qx }, { qy, -qx, qw } };
+    for (int row = 0; row < 2; ++row) {
+        const double* g = G[row];
+        if (Jc) {
+            double* o = Jc + 6 * row;
+            o[0] = g[0];
+            o[1] = g[1];
+            o[2] = g[2];
+            for (int k = 0; k < 3; ++k) {
+                double v = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    double dk = 0.0;
+                    for (int b = 0; b < 4; ++b)
+                        dk += Dq[a][b] * Gq[b][k];
+                    v += g[a] * dk;
+                }
+                o[3 + k] = v;
+            }
+        }
+        if (Jp)
+            for (int k = 0; k < 3; ++k)
+                Jp[3 * row + k] = g[0] * Ru[0 + k] + g[1] * Ru[3 + k] + g[2] * Ru[6 + k];
+    }
+}
+
+/* One "observation" of the point variant: the two corners of a point pair (see vo_problem.landmark_points). */
+static void obs_eval_point_pair(const double intr[4], const double dist[5], const double cam_qt[7],
+                                const double pair[6], const double px[4], double r[8], double* Jc, double* Jt)
+{
+    memset(r, 0, 8 * sizeof(double));
+    if (Jc)
+        memset(Jc, 0, 48 * sizeof(double));
+    if (Jt)
+        memset(Jt, 0, 48 * sizeof(double));
+    for (int i = 0; i < 2; ++i) {
+        double jc[12], jp[6];
+        vo_point_eval(intr, dist, cam_qt, pair + 3 * i, px + 2 * i, r + 2 * i, Jc ? jc : NULL, Jt ? jp : NULL);
+        for (int row = 0; row < 2; ++row) {
+            if (Jc)
+                memcpy(Jc + 6 * (2 * i + row), jc + 6 * row, 6 * sizeof(double));
+            if (Jt)
+                memcpy(Jt + 6 * (2 * i + row) + 3 * i, jp + 3 * row, 3 * sizeof(double));
+        }
+    }
+}
+
+/* the residual block(s) of observation i in either landmark model */
+static void obs_eval(const vo_problem* p, const double* cam_qt, const double* tag_qt, int i, double r[8],
+                     double* Jc, double* Jt)
+{
+    const int c = p->obs_cam[i], t = p->obs_tag[i];
+    if (p->landmark_points)
+        obs_eval_point_pair(p->intr, p->dist, cam_qt + 7 * c, tag_qt + 7 * t, p->obs_px + 8 * i, r, Jc, Jt);
+    else
+        vo_obs_eval(p->intr, p->dist, cam_qt + 7 * c, tag_qt + 7 * t, p->tag_wh + 2 * t, p->obs_px + 8 * i, r, Jc, Jt);
+}
+
+/* Plus of a landmark block: quaternion + translation (tag poses) or plain addition (a pair of points) */
+static void landmark_plus(int landmark_points, const double x[7], const double d[6], double out[7])
+{
+    if (!landmark_points) {
+        vo_pose_plus(x, d, out);
+        return;
+    }
+    for (int k = 0; k < 6; ++k)
+        out[k] = x[k] + d[k];
+    out[6] = x[6];
+}
+
 void vo_huber(double a, double s, double rho[3])
 {
     /* ceres::HuberLoss::Evaluate, constructed with a=1.0 at TagReconstructor.cpp:721. */
@@ -307,9 +426,7 @@ static double cost_at(const vo_problem* p, const vo_options* o, const double* ca
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n_obs; ++i) {
         double r[8];
-        const int c = p->obs_cam[i], t = p->obs_tag[i];
-        vo_obs_eval(p->intr, p->dist, cam_qt + 7 * c, tag_qt + 7 * t, p->tag_wh + 2 * t,
-                    p->obs_px + 8 * i, r, NULL, NULL);
+        obs_eval(p, cam_qt, tag_qt, i, r, NULL, NULL);
         part[i] = obs_cost(o, r);
     }
     double cost = 0.0;
@@ -406,6 +523,7 @@ static void chol_solve(const double* L, int n, int lda, double* x)
 
 typedef struct work {
     int n_c, n_t, n_obs, n_pose, n_tan;
+    int landmark_points;
     double* J;       /* per observation: Jc[48] | Jt[48] (corrected; scaled after scaling step) */
     double* r;       /* per observation 8 corrected residuals */
     double* g;       /* tangent gradient (unscaled), 6 per pose; cameras first then tags */
@@ -423,12 +541,11 @@ static int eval_full(const vo_problem* p, const vo_options* o, work* w, const do
     double* part = (double*)calloc((size_t)(n_obs > 0 ? n_obs : 1), sizeof(double));
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n_obs; ++i) {
-        const int c = p->obs_cam[i], t = p->obs_tag[i];
+        const int t = p->obs_tag[i];
         double* Jc = w->J + (size_t)96 * i;
         double* Jt = Jc + 48;
         double* r = w->r + (size_t)8 * i;
-        vo_obs_eval(p->intr, p->dist, cam_qt + 7 * c, tag_qt + 7 * t, p->tag_wh + 2 * t,
-                    p->obs_px + 8 * i, r, Jc, Jt);
+        obs_eval(p, cam_qt, tag_qt, i, r, Jc, Jt);
         if (!w->active[p->n_cams + t])
             memset(Jt, 0, 48 * sizeof(double));
         part[i] = obs_cost(o, r);
@@ -770,7 +887,10 @@ static void gradient_norms(const work* w, const double* cam_qt, const double* ta
         double ng[6], xp[7];
         for (int a = 0; a < 6; ++a)
             ng[a] = -w->g[6 * k + a];
-        vo_pose_plus(x, ng, xp);
+        if (k < w->n_c)
+            vo_pose_plus(x, ng, xp);
+        else
+            landmark_plus(w->landmark_points, x, ng, xp);
         for (int a = 0; a < 7; ++a) {
             const double d = fabs(x[a] - xp[a]);
             if (d > mx)
@@ -800,6 +920,7 @@ int vo_solve(vo_problem* p, const vo_options* o, vo_summary* s)
     w.n_obs = n_obs;
     w.n_pose = n_c + n_t;
     w.n_tan = 6 * w.n_pose;
+    w.landmark_points = p->landmark_points;
 #ifdef _OPENMP
     if (o->num_threads > 0)
         omp_set_num_threads(o->num_threads);
@@ -832,6 +953,8 @@ int vo_solve(vo_problem* p, const vo_options* o, vo_summary* s)
     }
     if (p->fixed_tag >= 0 && p->fixed_tag < n_t)
         w.active[n_c + p->fixed_tag] = 0;
+    if (p->landmark_points && p->fixed_tag2 >= 0 && p->fixed_tag2 < n_t)
+        w.active[n_c + p->fixed_tag2] = 0;
 
     int solver = o->linear_solver;
     if (solver == VO_SOLVER_SCHUR_AUTO)
@@ -970,7 +1093,7 @@ int vo_solve(vo_problem* p, const vo_options* o, vo_summary* s)
         for (int c = 0; c < n_c; ++c)
             vo_pose_plus(x_c + 7 * c, w.delta + 6 * c, cand_c + 7 * c);
         for (int t = 0; t < n_t; ++t)
-            vo_pose_plus(x_t + 7 * t, w.delta + 6 * (n_c + t), cand_t + 7 * t);
+            landmark_plus(p->landmark_points, x_t + 7 * t, w.delta + 6 * (n_c + t), cand_t + 7 * t);
         t0 = now_s();
         double cand_cost = cost_at(p, o, cand_c, cand_t);
         s->num_cost_evals++;
@@ -1175,6 +1298,8 @@ int vo_tag_translation_covariance(const vo_problem* p, const vo_options* o, doub
     }
     if (p->fixed_tag >= 0 && p->fixed_tag < n_t)
         w.active[n_c + p->fixed_tag] = 0;
+    if (p->landmark_points && p->fixed_tag2 >= 0 && p->fixed_tag2 < n_t)
+        w.active[n_c + p->fixed_tag2] = 0;
     double cost = 0.0;
     eval_full(p, o, &w, p->cam_qt, p->tag_qt, &cost);
     double* D2 = (double*)calloc((size_t)n + 1, sizeof(double));

@@ -41,6 +41,14 @@ typedef struct vo_problem {
     const int* obs_cam;    /* [n_obs] dense camera index */
     const int* obs_tag;    /* [n_obs] dense tag index */
     const double* obs_px;  /* [8*n_obs] LL,LR,UR,UL x (u,v)          DetectionIO.cpp:45-51, README.md:216 */
+    /* Point-landmark variant (OpenCVReprojectionError, TagReconstructionCostFunction.h:9-84, used by the dead
+     * doBundleAdjustment_points, src/TagReconstructor.cpp:457-644): landmark_points != 0 turns every "tag" slot
+     * into a PAIR of free 3-D points -- tag_qt[7*t .. 7*t+5] = (point a, point b), slot 6 unused -- and every
+     * observation into the two corner observations of those points (obs_px[8*i .. 8*i+3]; the rest unused).  Two
+     * points share a 6-dof block only for storage: their 3x3 blocks do not couple, every solver gives the step of
+     * Ceres' 3-dof point blocks.  fixed_tag2 = a second constant block (the origin tag has two pairs), or -1. */
+    int landmark_points;
+    int fixed_tag2;
 } vo_problem;
 
 enum { VO_SOLVER_DENSE_NORMAL = 0, VO_SOLVER_SCHUR_ELIM_TAGS = 1, VO_SOLVER_SCHUR_ELIM_CAMS = 2,
@@ -117,6 +125,11 @@ void vo_huber(double a, double s, double rho[3]);
 
 /* Ceres QuaternionParameterization::Plus on one pose: t += d[0..2]; q = exp(d[3..5]) (x) q. */
 void vo_pose_plus(const double qt[7], const double delta[6], double out[7]);
+
+/* OpenCVReprojectionError::operator() (TagReconstructionCostFunction.h:21-68) for one (camera, point, corner):
+ * residual[2]; optional tangent Jacobians Jc[2][6] (camera t, then half-angle rotation) and Jp[2][3] (point). */
+void vo_point_eval(const double intr[4], const double dist[5], const double cam_qt[7], const double point[3],
+                   const double obs_uv[2], double residual[2], double* Jc, double* Jp);
 
 /* Total cost 1/2 sum rho(|r|^2) over all corner blocks (Ceres Evaluator, cost only). */
 double vo_cost(const vo_problem* p, const vo_options* o);

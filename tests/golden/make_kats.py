@@ -63,6 +63,29 @@ def corner_residual(intr, dist, cam, tag, cl, uv):
     return [intr[0] * xd + intr[2] - uv[0], intr[1] * yd + intr[3] - uv[1]]
 
 
+def unit_quat_rotate(q, p):
+    """ceres::UnitQuaternionRotatePoint: the rotation polynomial of q WITHOUT normalisation
+    (TagReconstructionCostFunction.h:27, OpenCVReprojectionError)."""
+    w, x, y, z = q
+    R = [[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]]
+    return [sum(R[i][k] * p[k] for k in range(3)) for i in range(3)]
+
+
+def point_residual(intr, dist, cam, pt, uv):
+    """OpenCVReprojectionError::operator(), TagReconstructionCostFunction.h:21-68."""
+    pc = unit_quat_rotate(cam[:4], pt)
+    pc = [pc[i] + cam[4 + i] for i in range(3)]
+    x, y = pc[0] / pc[2], pc[1] / pc[2]
+    r2 = x * x + y * y
+    k1, k2, p1, p2, k3 = dist
+    rad = 1 + r2 * (k1 + r2 * (k2 + r2 * k3))
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + 2 * p2 * x * y + p1 * (r2 + 2 * y * y)
+    return [intr[0] * xd + intr[2] - uv[0], intr[1] * yd + intr[3] - uv[1]]
+
+
 def project_camera_model(intr, dist, pc):
     """CameraModel::projectPoint, /root/reference/src/CameraModel.cpp:6-26, statement by statement: pt.x() is
     overwritten at :20-21 BEFORE :22-23 evaluates 2*p2*pt.x()*pt.y(), so the y term sees the DISTORTED x
@@ -217,8 +240,52 @@ def main():
                               [mpf(0), mpf(0), mpf(0)], [mpf(0), mpf(0)])
         project.append({"intr": intr, "dist": dist, "point_cam": pc, "uv": [float(v) for v in uv],
                         "uv_functor_formula": [float(v) for v in fun]})
+    # Point-landmark functor (OpenCVReprojectionError): residual and tangent Jacobians w.r.t. the camera
+    # (translation, then half-angle rotation through Plus) and the 3-D point; case 2 and 3 carry a camera quaternion
+    # that is NOT unit (UnitQuaternionRotatePoint does not normalise: the result scales with |q|^2)
+    rng3 = random.Random(20261006)
+    point_cases = []
+    for pi in range(8):
+        dist = dist_readme if pi % 2 else [0.0] * 5
+        qs = rand_quat(rng3, small=True)
+        qx = [0.0, 1.0, 0.0, 0.0]
+        cam_q = [qs[0] * qx[0] - qs[1] * qx[1] - qs[2] * qx[2] - qs[3] * qx[3],
+                 qs[0] * qx[1] + qs[1] * qx[0] + qs[2] * qx[3] - qs[3] * qx[2],
+                 qs[0] * qx[2] - qs[1] * qx[3] + qs[2] * qx[0] + qs[3] * qx[1],
+                 qs[0] * qx[3] + qs[1] * qx[2] - qs[2] * qx[1] + qs[3] * qx[0]]
+        if pi in (2, 3):
+            cam_q = [c * 1.05 for c in cam_q]
+        cam = cam_q + [rng3.uniform(-0.5, 0.5), rng3.uniform(-0.4, 0.4), rng3.uniform(2.5, 4.0)]
+        pt = [rng3.uniform(-1, 1), rng3.uniform(-0.6, 0.6), rng3.gauss(0, 0.05)]
+        camm, ptm = [mpf(c) for c in cam], [mpf(c) for c in pt]
+        intrm, distm = [mpf(c) for c in intr], [mpf(c) for c in dist]
+        r0 = point_residual(intrm, distm, camm, ptm, [mpf(0), mpf(0)])
+        uv = [float(r0[0]) + rng3.gauss(0, 1.5), float(r0[1]) + rng3.gauss(0, 1.5)]
+        uvm = [mpf(c) for c in uv]
+        res = point_residual(intrm, distm, camm, ptm, uvm)
+        Jc, Jp = [], []
+        for comp in range(2):
+            rowc, rowp = [], []
+            for a in range(6):
+                def fc(e, a=a, comp=comp):
+                    d = [mpf(0)] * 6
+                    d[a] = e
+                    return point_residual(intrm, distm, plus(camm, d), ptm, uvm)[comp]
+                rowc.append(diff(fc, mpf(0)))
+            for a in range(3):
+                def fp(e, a=a, comp=comp):
+                    q = list(ptm)
+                    q[a] = q[a] + e
+                    return point_residual(intrm, distm, camm, q, uvm)[comp]
+                rowp.append(diff(fp, mpf(0)))
+            Jc.append(rowc)
+            Jp.append(rowp)
+        point_cases.append({"intr": intr, "dist": dist, "cam_qt": cam, "point": pt, "uv": uv,
+                            "residual": [float(v) for v in res],
+                            "J_cam": [[float(v) for v in row] for row in Jc],
+                            "J_point": [[float(v) for v in row] for row in Jp]})
     out = {"generator": "tests/golden/make_kats.py (mpmath %d digits)" % mp.dps,
-           "obs": cases, "plus": plus_cases, "huber": huber, "project_point": project}
+           "obs": cases, "plus": plus_cases, "huber": huber, "project_point": project, "point_obs": point_cases}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_residual.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)

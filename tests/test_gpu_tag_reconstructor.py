@@ -111,3 +111,31 @@ def test_reprojection_stats_match_camera_model_kats(kats):
         np.testing.assert_allclose(corner[0], ref, rtol=0, atol=2e-9)
         mean = np.sqrt((ref.reshape(4, 2) ** 2).sum(axis=1)).sum() / 4
         np.testing.assert_allclose([pc[0], pt[0], avg], mean, rtol=1e-12)
+
+
+def test_do_bundle_adjustment_points_matches_oracle(oracle, capsys):
+    """TagReconstructor.doBundleAdjustment_points (src/TagReconstructor.cpp:457-644) with sparse ids."""
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1)
+    tag_ids = [230 + 3 * k for k in range(len(s.tag_init))]
+    cam_ids = [1000 - 7 * k for k in range(len(s.cam_init))]
+    rec = _make(s, tag_ids, cam_ids)
+    rec.doBundleAdjustment_points(400, 4, False)
+    assert "Solution 0" in capsys.readouterr().out
+    sc, pts0 = oracle.point_scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                                  s.obs_px)
+    summ, _ = oracle.solve(sc, oracle.default_options(robustify=0, linear_solver=oracle.DENSE_NORMAL))
+    assert rec.lastSummary["iterations"] == summ["iterations"]
+    np.testing.assert_allclose(rec.lastSummary["final_cost"], summ["final_cost"], rtol=1e-8)
+    ref = oracle.scene_points(sc)
+    for k, tid in enumerate(tag_ids):
+        np.testing.assert_allclose(rec.lastPoints[tid], ref[k], rtol=0, atol=1e-6 * np.abs(ref).max())
+        # the rebuilt pose puts the tag centre at the mean of its corners (:633)
+        np.testing.assert_allclose(rec.reconstructedTags[tid].t, ref[k].mean(axis=0), rtol=0, atol=1e-9)
+    for k, cid in enumerate(cam_ids):
+        np.testing.assert_allclose(np.r_[rec.reconstructedCameras[cid].q, rec.reconstructedCameras[cid].t], sc.cam_qt[k],
+                                   rtol=0, atol=1e-6 * np.abs(sc.cam_qt).max())
+    np.testing.assert_array_equal(rec.lastPoints[tag_ids[0]], pts0[0])          # origin tag constant
+    # the tag-pose bundle adjustment still runs on the same object afterwards
+    rec.doBundleAdjustment(400, 1, False)
+    assert rec.lastSummary["termination_type"] == 0

@@ -57,3 +57,18 @@ def test_reprojection_statistics_match_camera_model_kats(oracle, kats):
         np.testing.assert_allclose(corner[0], ref, rtol=0, atol=2e-9)
         mean = np.sqrt((ref.reshape(4, 2) ** 2).sum(axis=1)).sum() / 4
         np.testing.assert_allclose([pc[0], pt[0], avg], mean, rtol=1e-12)
+
+
+def test_point_functor_matches_mpmath(oracle, kats):
+    # OpenCVReprojectionError (TagReconstructionCostFunction.h:21-68): UnitQuaternionRotatePoint does not normalise
+    # the camera quaternion -- cases 2 and 3 carry |q| = 1.05
+    for case in kats["point_obs"]:
+        r, Jc, Jp = oracle.point_eval(case["intr"], case["dist"], case["cam_qt"], case["point"], case["uv"])
+        np.testing.assert_allclose(r, case["residual"], rtol=0, atol=2e-9)
+        for J, ref in ((Jc, np.array(case["J_cam"])), (Jp, np.array(case["J_point"]))):
+            np.testing.assert_allclose(J, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    # and it really differs from the normalising tag functor on a non-unit quaternion
+    c = kats["point_obs"][2]
+    tag = [1.0, 0.0, 0.0, 0.0] + list(c["point"])
+    r_tag = oracle.obs_eval(c["intr"], c["dist"], c["cam_qt"], tag, [0.0, 0.0], list(c["uv"]) * 4, jac=False)[:2]
+    assert np.abs(r_tag - np.array(c["residual"])).max() > 1.0

@@ -105,3 +105,44 @@ def test_max_iterations_gives_no_convergence(oracle):
     summ, trace = oracle.solve(sc, oracle.default_options(max_num_iterations=2))
     assert summ["termination_type"] == oracle.NO_CONVERGENCE
     assert summ["iterations"] == 3 and trace[-1]["iteration"] == 2
+
+
+def _point_scene(oracle, s, init=True):
+    cam = s.cam_init if init else s.cam_gt
+    tag = s.tag_init if init else s.tag_gt
+    return oracle.point_scene(s.intr, s.dist, cam, tag, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+
+
+def test_point_landmark_solvers_agree(oracle):
+    """doBundleAdjustment_points (src/TagReconstructor.cpp:457-644): cameras x free 3-D points.  The dense normal
+    equations and both block eliminations are three routes to the same LM step."""
+    s = make_scene(1)
+    res = []
+    for solver in (oracle.DENSE_NORMAL, oracle.SCHUR_ELIM_TAGS, oracle.SCHUR_ELIM_CAMS):
+        sc, _ = _point_scene(oracle, s)
+        summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, linear_solver=solver))
+        assert summ["termination_type"] == oracle.CONVERGENCE
+        res.append((summ, trace, sc.cam_qt.copy(), oracle.scene_points(sc).copy()))
+    for summ, trace, cam, pts in res[1:]:
+        assert summ["iterations"] == res[0][0]["iterations"]
+        np.testing.assert_allclose([t["cost"] for t in trace], [t["cost"] for t in res[0][1]], rtol=1e-9)
+        np.testing.assert_allclose(cam, res[0][2], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(pts, res[0][3], rtol=0, atol=1e-8)
+    # the origin tag's four corners are constant (:494-497), 8 residuals per tag observation, more freedom than the
+    # tag-pose model (12 instead of 6 parameters per tag): a lower optimum on the same detections
+    sc, pts0 = _point_scene(oracle, s)
+    np.testing.assert_array_equal(res[0][3][s.fixed_tag], pts0[s.fixed_tag])
+    sct = _scene(oracle, s)
+    summ_t, _ = oracle.solve(sct, oracle.default_options(robustify=0))
+    assert res[0][0]["final_cost"] < summ_t["final_cost"]
+    assert res[0][0]["initial_cost"] == pytest.approx(summ_t["initial_cost"], rel=1e-9)   # same corners, same poses
+
+
+def test_point_landmark_zero_noise_recovers_the_corners(oracle):
+    s = make_scene(1, noise_px=0.0)
+    sc, _ = _point_scene(oracle, s)
+    summ, _ = oracle.solve(sc, oracle.default_options(robustify=0, function_tolerance=1e-16, parameter_tolerance=1e-14,
+                                                      max_num_iterations=60))
+    _, gt = _point_scene(oracle, s, init=False)
+    assert summ["final_cost"] < 1e-10
+    np.testing.assert_allclose(oracle.scene_points(sc), gt, rtol=0, atol=1e-8)

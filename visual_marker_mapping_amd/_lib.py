@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("VMM_BA_LIB") or os.path.join(_HERE, "libvmm_ba.so")
 ABI_VERSION = 2          # VMM_BA_ABI_VERSION of include/vmm_ba.h
 RCCL_ID_BYTES = 128      # VMM_BA_RCCL_ID_BYTES
 PRECISION_F64, PRECISION_F32_ACCUM = 0, 1
+LANDMARK_TAG_POSES, LANDMARK_POINTS = 0, 1
 OK, ERR_ARGUMENT, ERR_HIP, ERR_COLLECTIVE, ERR_STATE, ERR_NUMERIC = 0, 1, 2, 3, 4, 5
 ELIM_AUTO, ELIM_TAGS, ELIM_CAMERAS = 0, 1, 2
 CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
@@ -19,7 +20,7 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 # every symbol include/vmm_ba.h declares
 EXPORTS = ["vmm_ba_last_error", "vmm_ba_abi_version", "vmm_ba_default_options",
            "vmm_ba_default_create_options", "vmm_ba_create", "vmm_ba_destroy", "vmm_ba_set_state",
-           "vmm_ba_get_state", "vmm_ba_set_allreduce", "vmm_ba_rccl_unique_id", "vmm_ba_enable_rccl",
+           "vmm_ba_get_state", "vmm_ba_get_points", "vmm_ba_set_allreduce", "vmm_ba_rccl_unique_id", "vmm_ba_enable_rccl",
            "vmm_ba_set_observation_mask", "vmm_ba_solve", "vmm_ba_cost",
            "vmm_ba_reprojection_stats", "vmm_ba_tag_translation_covariance", "vmm_ba_project_points", "vmm_ba_eval_blocks",
            "vmm_ba_dense_spd_solve", "vmm_ba_dense_syrk", "vmm_ba_time_kernels"]
@@ -35,7 +36,7 @@ class Problem(C.Structure):
 
 class CreateOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("elimination", C.c_int32), ("rank", C.c_int32),
-                ("world_size", C.c_int32), ("precision", C.c_int32)]
+                ("world_size", C.c_int32), ("precision", C.c_int32), ("landmarks", C.c_int32)]
 
 
 class Options(C.Structure):
@@ -103,6 +104,7 @@ def lib():
         L.vmm_ba_create.argtypes = [C.POINTER(Problem), C.POINTER(CreateOptions), C.POINTER(C.c_void_p)]
         L.vmm_ba_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.vmm_ba_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vmm_ba_get_points.argtypes = [C.c_void_p, C.c_void_p]
         L.vmm_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
         L.vmm_ba_rccl_unique_id.argtypes = [C.c_void_p]
         L.vmm_ba_enable_rccl.argtypes = [C.c_void_p, C.c_void_p]

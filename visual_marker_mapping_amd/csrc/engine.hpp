@@ -97,6 +97,12 @@ struct Engine {
 
     Intrinsics K;
     int n_cams = 0, n_tags = 0, fixed_tag = -1;
+    // point landmarks (VMM_BA_LANDMARK_POINTS): the "tag" family holds 2 * n_tags_user point pairs, the observation
+    // arrays 2 * n_obs_user pair observations; fixed_tag stays the caller's tag index (block >> 1 is compared)
+    bool points = false;
+    int n_tags_user = 0;
+    int64_t n_obs_user = 0;
+    std::vector<double> user_tag_wh;   // [2 * n_tags_user]: vmm_ba_set_state turns tag poses into corners again
     int64_t n_obs = 0;
     bool elim_cams = true;          // eliminated family E = cameras (else tags)
     int n_e = 0, n_f = 0;           // pose counts of the eliminated / kept family

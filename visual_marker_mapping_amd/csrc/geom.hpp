@@ -140,6 +140,80 @@ __device__ __forceinline__ void eval_corner(const Intrinsics& K, const Rigid& ca
     }
 }
 
+// Point-landmark functor: OpenCVReprojectionError::operator() (CostFunction.h:21-68), the residual of the dead
+// doBundleAdjustment_points (src/TagReconstructor.cpp:457-644).  The camera rotation is
+// ceres::UnitQuaternionRotatePoint (:27): the polynomial R_u(q) = I + 2 M(q) of the quaternion AS IT IS, no
+// normalisation (cam.R comes from load_rigid<false>).  Jacobians as AutoDiffCostFunction<..., 2, 3, 4, 3> (:74-75)
+// + QuaternionParameterization (src/TagReconstructor.cpp:529) give them: d/d(point) = A R_u(q) and
+// d/d(delta) = A [d R_u(q) p / dq] G(q), G = the 4x3 Jacobian of Plus at delta = 0.
+// e.jt[r][0..2] receives the point Jacobian (3 columns); e.jt[r][3..5] is not written.
+template <bool NEED_JC, bool NEED_JP>
+__device__ __forceinline__ void eval_point(const Intrinsics& K, const Rigid& cam, const double* __restrict__ camq,
+                                           const double p0, const double p1, const double p2, double u_obs,
+                                           double v_obs, CornerEval& e, const bool on = true)
+{
+    const double b0 = cam.R[0] * p0 + cam.R[1] * p1 + cam.R[2] * p2;
+    const double b1 = cam.R[3] * p0 + cam.R[4] * p1 + cam.R[5] * p2;
+    const double b2 = cam.R[6] * p0 + cam.R[7] * p1 + cam.R[8] * p2;
+    const double X = b0 + cam.t[0], Y = b1 + cam.t[1], Z = b2 + cam.t[2];   // :27-31
+    const double iz = on ? 1.0 / Z : 0.0;
+    const double x = X * iz, y = Y * iz;             // :34-35
+    const double r2 = x * x + y * y;                 // :38
+    const double rad = 1.0 + r2 * (K.k1 + r2 * (K.k2 + r2 * K.k3));
+    double xd, yd;
+    distort(K, false, x, y, r2, rad, xd, yd);        // :49-54
+    e.ru = K.fx * xd + K.cx - u_obs;                 // :61-67
+    e.rv = K.fy * yd + K.cy - v_obs;
+    if (!NEED_JC && !NEED_JP)
+        return;
+    const double dr = K.k1 + r2 * (2.0 * K.k2 + 3.0 * K.k3 * r2);
+    const double D00 = rad + 2.0 * x * x * dr + 2.0 * K.p1 * y + 6.0 * K.p2 * x;
+    const double D01 = 2.0 * x * y * dr + 2.0 * K.p1 * x + 2.0 * K.p2 * y;
+    const double D11 = rad + 2.0 * y * y * dr + 2.0 * K.p2 * x + 6.0 * K.p1 * y;
+    double g[2][3];
+    g[0][0] = K.fx * D00 * iz;
+    g[0][1] = K.fx * D01 * iz;
+    g[0][2] = -K.fx * (D00 * x + D01 * y) * iz;
+    g[1][0] = K.fy * D01 * iz;
+    g[1][1] = K.fy * D11 * iz;
+    g[1][2] = -K.fy * (D01 * x + D11 * y) * iz;
+    double dk[3][3];   // d(R_u p)/d(delta): [component][tangent direction]
+    if (NEED_JC) {
+        const double qw = camq[0], qx = camq[1], qy = camq[2], qz = camq[3];
+        // columns of d(R_u p)/d(w, x, y, z)
+        const double dq[3][4] = {
+            { 2.0 * (qy * p2 - qz * p1), 2.0 * (qy * p1 + qz * p2), 2.0 * (-2.0 * qy * p0 + qx * p1 + qw * p2),
+              2.0 * (-2.0 * qz * p0 - qw * p1 + qx * p2) },
+            { 2.0 * (qz * p0 - qx * p2), 2.0 * (qy * p0 - 2.0 * qx * p1 - qw * p2), 2.0 * (qx * p0 + qz * p2),
+              2.0 * (qw * p0 - 2.0 * qz * p1 + qy * p2) },
+            { 2.0 * (qx * p1 - qy * p0), 2.0 * (qz * p0 + qw * p1 - 2.0 * qx * p2), 2.0 * (-qw * p0 + qz * p1 - 2.0 * qy * p2),
+              2.0 * (qx * p0 + qy * p1) } };
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            dk[a][0] = -dq[a][0] * qx + dq[a][1] * qw - dq[a][2] * qz + dq[a][3] * qy;
+            dk[a][1] = -dq[a][0] * qy + dq[a][1] * qz + dq[a][2] * qw - dq[a][3] * qx;
+            dk[a][2] = -dq[a][0] * qz - dq[a][1] * qy + dq[a][2] * qx + dq[a][3] * qw;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double g0 = g[r][0], g1 = g[r][1], g2 = g[r][2];
+        if (NEED_JC) {
+            e.jc[r][0] = g0;
+            e.jc[r][1] = g1;
+            e.jc[r][2] = g2;
+            e.jc[r][3] = g0 * dk[0][0] + g1 * dk[1][0] + g2 * dk[2][0];
+            e.jc[r][4] = g0 * dk[0][1] + g1 * dk[1][1] + g2 * dk[2][1];
+            e.jc[r][5] = g0 * dk[0][2] + g1 * dk[1][2] + g2 * dk[2][2];
+        }
+        if (NEED_JP) {
+            e.jt[r][0] = g0 * cam.R[0] + g1 * cam.R[3] + g2 * cam.R[6];
+            e.jt[r][1] = g0 * cam.R[1] + g1 * cam.R[4] + g2 * cam.R[7];
+            e.jt[r][2] = g0 * cam.R[2] + g1 * cam.R[5] + g2 * cam.R[8];
+        }
+    }
+}
+
 // ceres::HuberLoss(a)::Evaluate on s = |r|^2 (src/TagReconstructor.cpp:721): returns rho(s) and the
 // row weight sqrt(rho'(s)) the Ceres corrector applies when rho'' <= 0.
 __device__ __forceinline__ void huber(bool robust, double a, double s, double& rho0, double& wgt)

@@ -27,6 +27,7 @@ struct EvalArgs {
     const double* other_pose;  // poses of the other family
     const double* tag_wh;
     int fixed_tag;
+    int fixed_shift;           // point landmarks: two 6-dof blocks (point pairs) per tag, block >> 1 == fixed_tag
     int robustify;
     double huber_a;
     double* part;              // [n_tasks][kPart]
@@ -41,7 +42,10 @@ __device__ __forceinline__ int tri(int a, int b) { return a * (a + 1) / 2 + b; }
 
 // AT: accumulation/storage type of the J^T J blocks (double, or float for VMM_BA_PRECISION_F32_ACCUM);
 // residuals, the cost and the gradient J^T r are always f64.
-template <bool OWN_IS_CAM, bool WRITE_W, typename AT>
+// POINTS: the landmark family holds pairs of free 3-D points (vmm_ba_create_options.landmarks ==
+// VMM_BA_LANDMARK_POINTS): an observation is the two corner observations of one pair, each corner is
+// OpenCVReprojectionError (CostFunction.h:21-68) and touches three of the block's six columns.
+template <bool OWN_IS_CAM, bool WRITE_W, typename AT, bool POINTS = false>
 __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
 {
     const int lane = threadIdx.x & 63;
@@ -53,15 +57,24 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
     const int64_t is = valid ? i : t.begin;
     const int o = a.other[is];
 
-    Rigid own, oth;
-    load_rigid<true>(a.own_pose + 7 * (int64_t)t.pose, own);
-    load_rigid<true>(a.other_pose + 7 * (int64_t)o, oth);
-    const Rigid& cam = OWN_IS_CAM ? own : oth;
-    const Rigid& tag = OWN_IS_CAM ? oth : own;
     const int tag_idx = OWN_IS_CAM ? o : t.pose;
-    const double hw = 0.5 * a.tag_wh[2 * tag_idx], hh = 0.5 * a.tag_wh[2 * tag_idx + 1];
-    // a constant (origin) tag contributes no Jacobian columns (src/TagReconstructor.cpp:669-673)
-    const double tag_on = (tag_idx == a.fixed_tag) ? 0.0 : 1.0;
+    const int cam_idx = OWN_IS_CAM ? t.pose : o;
+    const double* camq = (OWN_IS_CAM ? a.own_pose : a.other_pose) + 7 * (int64_t)cam_idx;
+    const double* tagq = (OWN_IS_CAM ? a.other_pose : a.own_pose) + 7 * (int64_t)tag_idx;
+    Rigid cam, tag;
+    double pt[6];
+    if (POINTS) {
+        load_rigid<false>(camq, cam);   // UnitQuaternionRotatePoint: the quaternion as it is
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            pt[k] = tagq[k];
+    } else {
+        load_rigid<true>(camq, cam);
+        load_rigid<true>(tagq, tag);
+    }
+    const double hw = POINTS ? 0.0 : 0.5 * a.tag_wh[2 * tag_idx], hh = POINTS ? 0.0 : 0.5 * a.tag_wh[2 * tag_idx + 1];
+    // a constant (origin) tag contributes no Jacobian columns (src/TagReconstructor.cpp:669-673, :494-497)
+    const double tag_on = ((tag_idx >> a.fixed_shift) == a.fixed_tag) ? 0.0 : 1.0;
     // switched-off observations are selected out, never multiplied out (their poses are parked defaults)
     const bool on = valid && a.mask[a.caller[is]];
 
@@ -83,14 +96,31 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
     constexpr bool NEED_JC = OWN_IS_CAM || WRITE_W;
     constexpr bool NEED_JT = !OWN_IS_CAM || WRITE_W;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < (POINTS ? 2 : 4); ++c) {
         // LL, LR, UR, UL (include/visual_marker_mapping/TagReconstructor.h:47-50)
         const double sx = (c == 1 || c == 2) ? hw : -hw;
         const double sy = (c >= 2) ? hh : -hh;
         const double u = a.px[(2 * c) * a.n_pad + is];
         const double v = a.px[(2 * c + 1) * a.n_pad + is];
         CornerEval e;
-        eval_corner<NEED_JC, NEED_JT>(a.K, cam, tag, sx, sy, u, v, e, on);
+        if (POINTS) {
+            eval_point<NEED_JC, NEED_JT>(a.K, cam, camq, pt[3 * c], pt[3 * c + 1], pt[3 * c + 2], u, v, e, on);
+            if (NEED_JT) {
+                // the corner's point owns columns 3c .. 3c+2 of the pair's block
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const double j0 = e.jt[r][0], j1 = e.jt[r][1], j2 = e.jt[r][2];
+                    e.jt[r][0] = c == 0 ? j0 : 0.0;
+                    e.jt[r][1] = c == 0 ? j1 : 0.0;
+                    e.jt[r][2] = c == 0 ? j2 : 0.0;
+                    e.jt[r][3] = c == 0 ? 0.0 : j0;
+                    e.jt[r][4] = c == 0 ? 0.0 : j1;
+                    e.jt[r][5] = c == 0 ? 0.0 : j2;
+                }
+            }
+        } else {
+            eval_corner<NEED_JC, NEED_JT>(a.K, cam, tag, sx, sy, u, v, e, on);
+        }
         const double s = e.ru * e.ru + e.rv * e.rv;
         double rho0, wgt;
         huber(a.robustify != 0, a.huber_a, s, rho0, wgt);
@@ -152,7 +182,7 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
         a.part[(int64_t)wave * kPart + slot] = mine;
 }
 
-template <bool OWN_IS_CAM, bool WRITE_W, typename AT = double>
+template <bool OWN_IS_CAM, bool WRITE_W, typename AT = double, bool POINTS = false>
 __global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
 {
     if (a.ctl) {
@@ -163,12 +193,12 @@ __global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
         if (WRITE_W)
             phase_stamp(a.ctl, 0);
     }
-    eval_body<OWN_IS_CAM, WRITE_W, AT>(a, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    eval_body<OWN_IS_CAM, WRITE_W, AT, POINTS>(a, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
 }
 
 // Both family passes in one launch: workgroups [0, nb_e) run the pass over the eliminated family (writes W),
 // the rest the pass over the kept family.  The passes are independent, so they share the chip.
-template <bool E_IS_CAM, typename AT = double>
+template <bool E_IS_CAM, typename AT = double, bool POINTS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_eval_both(const EvalArgs aE, const EvalArgs aF, const int nb_e)
 {
     if (aE.ctl) {
@@ -179,9 +209,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         phase_stamp(aE.ctl, 0);
     }
     if ((int)blockIdx.x < nb_e)
-        eval_body<E_IS_CAM, true, AT>(aE, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+        eval_body<E_IS_CAM, true, AT, POINTS>(aE, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     else
-        eval_body<!E_IS_CAM, false, AT>(aF, (int)(((blockIdx.x - nb_e) * blockDim.x + threadIdx.x) >> 6));
+        eval_body<!E_IS_CAM, false, AT, POINTS>(aF, (int)(((blockIdx.x - nb_e) * blockDim.x + threadIdx.x) >> 6));
 }
 
 // Sums the task partials of every pose in task order and expands the packed lower triangle.
@@ -278,7 +308,7 @@ struct CostArgs {
     const LmCtl* ctl;
 };
 
-template <bool OWN_IS_CAM>
+template <bool OWN_IS_CAM, bool POINTS = false>
 __global__ __launch_bounds__(256) void k_cost(const CostArgs a)
 {
     if (a.ctl && a.ctl->done)
@@ -292,21 +322,34 @@ __global__ __launch_bounds__(256) void k_cost(const CostArgs a)
     const bool valid = i < t.end;
     const int64_t is = valid ? i : t.begin;
     const int o = a.other[is];
-    Rigid own, oth;
-    load_rigid<true>(a.own_pose + 7 * (int64_t)t.pose, own);
-    load_rigid<true>(a.other_pose + 7 * (int64_t)o, oth);
-    const Rigid& cam = OWN_IS_CAM ? own : oth;
-    const Rigid& tag = OWN_IS_CAM ? oth : own;
     const int tag_idx = OWN_IS_CAM ? o : t.pose;
-    const double hw = 0.5 * a.tag_wh[2 * tag_idx], hh = 0.5 * a.tag_wh[2 * tag_idx + 1];
+    const int cam_idx = OWN_IS_CAM ? t.pose : o;
+    const double* camq = (OWN_IS_CAM ? a.own_pose : a.other_pose) + 7 * (int64_t)cam_idx;
+    const double* tagq = (OWN_IS_CAM ? a.other_pose : a.own_pose) + 7 * (int64_t)tag_idx;
+    Rigid cam, tag;
+    double pt[6];
+    if (POINTS) {
+        load_rigid<false>(camq, cam);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            pt[k] = tagq[k];
+    } else {
+        load_rigid<true>(camq, cam);
+        load_rigid<true>(tagq, tag);
+    }
+    const double hw = POINTS ? 0.0 : 0.5 * a.tag_wh[2 * tag_idx], hh = POINTS ? 0.0 : 0.5 * a.tag_wh[2 * tag_idx + 1];
     double cost = 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < (POINTS ? 2 : 4); ++c) {
         const double sx = (c == 1 || c == 2) ? hw : -hw;
         const double sy = (c >= 2) ? hh : -hh;
         CornerEval e;
-        eval_corner<false, false>(a.K, cam, tag, sx, sy, a.px[(2 * c) * a.n_pad + is],
-                                  a.px[(2 * c + 1) * a.n_pad + is], e);
+        if (POINTS)
+            eval_point<false, false>(a.K, cam, camq, pt[3 * c], pt[3 * c + 1], pt[3 * c + 2],
+                                     a.px[(2 * c) * a.n_pad + is], a.px[(2 * c + 1) * a.n_pad + is], e);
+        else
+            eval_corner<false, false>(a.K, cam, tag, sx, sy, a.px[(2 * c) * a.n_pad + is],
+                                      a.px[(2 * c + 1) * a.n_pad + is], e);
         double rho0, wgt;
         huber(a.robustify != 0, a.huber_a, e.ru * e.ru + e.rv * e.rv, rho0, wgt);
         cost += 0.5 * rho0;
@@ -440,6 +483,7 @@ static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, 
     a.other_pose = own_is_cam ? e.tag_qt : e.cam_qt;
     a.tag_wh = e.tag_wh;
     a.fixed_tag = e.fixed_tag;
+    a.fixed_shift = e.points ? 1 : 0;
     a.robustify = 0;
     a.huber_a = 1.0;
     a.part = ord.part;
@@ -463,7 +507,19 @@ void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, do
     if (a.n_tasks <= 0)
         return;
     const dim3 grid(blocks_for_tasks(a.n_tasks)), block(256);
-    if (e.f32_accum) {
+    if (e.points) {   // f64 only (vmm_ba_create refuses the combination with f32 accumulation)
+        if (elim_family) {
+            if (own_is_cam)
+                hipLaunchKernelGGL((k_eval<true, true, double, true>), grid, block, 0, e.stream, a);
+            else
+                hipLaunchKernelGGL((k_eval<false, true, double, true>), grid, block, 0, e.stream, a);
+        } else {
+            if (own_is_cam)
+                hipLaunchKernelGGL((k_eval<true, false, double, true>), grid, block, 0, e.stream, a);
+            else
+                hipLaunchKernelGGL((k_eval<false, false, double, true>), grid, block, 0, e.stream, a);
+        }
+    } else if (e.f32_accum) {
         if (elim_family) {
             if (own_is_cam)
                 hipLaunchKernelGGL((k_eval<true, true, float>), grid, block, 0, e.stream, a);
@@ -500,7 +556,12 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
         aE.ctl = aF.ctl = nullptr;
     const int nb_e = blocks_for_tasks(aE.n_tasks), nb_f = blocks_for_tasks(aF.n_tasks);
     if (nb_e + nb_f > 0) {
-        if (e.f32_accum) {
+        if (e.points) {
+            if (e_is_cam)
+                hipLaunchKernelGGL((k_eval_both<true, double, true>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
+            else
+                hipLaunchKernelGGL((k_eval_both<false, double, true>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
+        } else if (e.f32_accum) {
             if (e_is_cam)
                 hipLaunchKernelGGL((k_eval_both<true, float>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
             else
@@ -556,10 +617,16 @@ void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool gu
     a.ctl = guard ? e.ctl : nullptr;
     if (a.n_tasks <= 0)
         return;
-    if (e.elim_cams)
-        hipLaunchKernelGGL((k_cost<true>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);
+    const dim3 grid(blocks_for_tasks(a.n_tasks));
+    if (e.points) {
+        if (e.elim_cams)
+            hipLaunchKernelGGL((k_cost<true, true>), grid, dim3(256), 0, e.stream, a);
+        else
+            hipLaunchKernelGGL((k_cost<false, true>), grid, dim3(256), 0, e.stream, a);
+    } else if (e.elim_cams)
+        hipLaunchKernelGGL((k_cost<true>), grid, dim3(256), 0, e.stream, a);
     else
-        hipLaunchKernelGGL((k_cost<false>), dim3(blocks_for_tasks(a.n_tasks)), dim3(256), 0, e.stream, a);
+        hipLaunchKernelGGL((k_cost<false>), grid, dim3(256), 0, e.stream, a);
 }
 
 void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a,
@@ -622,6 +689,14 @@ int preload_eval_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, double>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<true, float>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, true, double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, true, double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, false, double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, false, double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<true, double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cost<true, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cost<false, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_pose)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_sum)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cost<true>)) != hipSuccess;

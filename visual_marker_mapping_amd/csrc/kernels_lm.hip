@@ -84,11 +84,26 @@ __device__ __forceinline__ void block_reduce_multi(double (&v)[NS + NM], double*
 
 struct PoseViews {
     int n_cams, n_tags;
+    int tag_euclid;   // point landmarks: a "tag" slot is a pair of 3-D points, Plus is plain addition of six numbers
     double* cam_qt;
     double* tag_qt;
     double* cam_cand;
     double* tag_cand;
 };
+
+// Plus of block p: cameras (and tag poses) = translation + QuaternionParameterization; point pairs = addition
+__device__ __forceinline__ void block_plus(const PoseViews& v, int p, const double* __restrict__ x, const double d[6],
+                                           double out[7])
+{
+    if (v.tag_euclid && p >= v.n_cams) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            out[k] = x[k] + d[k];
+        out[6] = x[6];
+    } else {
+        pose_plus(x, d, out);
+    }
+}
 
 __device__ __forceinline__ double* pose_ptr(const PoseViews& v, int p, bool cand)
 {
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, c
                 double ng[6], xp[7];
                 for (int k = 0; k < 6; ++k)
                     ng[k] = -g[6 * (int64_t)p + k];
-                pose_plus(x, ng, xp);
+                block_plus(pv, p, x, ng, xp);
                 for (int k = 0; k < 7; ++k)
                     gm = fmax(gm, fabs(x[k] - xp[k]));
             }
@@ -360,7 +375,7 @@ __global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_p
     }
     const double* x = pose_ptr(pv, p, false);
     double out[7];
-    pose_plus(x, d, out);
+    block_plus(pv, p, x, d, out);
     double* c = pose_ptr(pv, p, true);
     double sn = 0.0, xn = 0.0;
     for (int k = 0; k < 7; ++k) {
@@ -535,6 +550,7 @@ static PoseViews views(Engine& e)
     PoseViews pv;
     pv.n_cams = e.n_cams;
     pv.n_tags = e.n_tags;
+    pv.tag_euclid = e.points ? 1 : 0;
     pv.cam_qt = e.cam_qt;
     pv.tag_qt = e.tag_qt;
     pv.cam_cand = e.cam_cand;

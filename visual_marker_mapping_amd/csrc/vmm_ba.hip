@@ -325,6 +325,99 @@ static int setup_lookahead(Engine& e, int n_blk_max, int ld)
     return VMM_BA_OK;
 }
 
+// ---- point landmarks: tag pose <-> its four world corners ----
+// computeMarkerCorners3D (include/visual_marker_mapping/TagReconstructor.h:33-52, called at
+// src/TagReconstructor.cpp:483): R = Eigen::Quaterniond::toRotationMatrix() (no normalisation), corner = R local + t,
+// corners LL, LR, UR, UL.
+static void tag_to_points(const double* qt, const double* wh, double* pts)
+{
+    const double w = qt[0], x = qt[1], y = qt[2], z = qt[3];
+    const double R[9] = { 1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y - w * z), 2.0 * (x * z + w * y),
+                          2.0 * (x * y + w * z), 1.0 - 2.0 * (x * x + z * z), 2.0 * (y * z - w * x),
+                          2.0 * (x * z - w * y), 2.0 * (y * z + w * x), 1.0 - 2.0 * (x * x + y * y) };
+    static const double sx[4] = { -1.0, 1.0, 1.0, -1.0 }, sy[4] = { -1.0, -1.0, 1.0, 1.0 };
+    for (int k = 0; k < 4; ++k) {
+        const double lx = sx[k] * wh[0] / 2.0, ly = sy[k] * wh[1] / 2.0;
+        for (int a = 0; a < 3; ++a)
+            pts[3 * k + a] = (R[3 * a] * lx + R[3 * a + 1] * ly) + qt[4 + a];
+    }
+}
+
+// The tag pose of four optimised corners, src/TagReconstructor.cpp:608-639: x along corner 0 -> 1, y along corner
+// 0 -> 3, z = x cross y, t = the mean of the corners.  The dead code stores R.col(0) = y, R.col(1) = -x (its comments
+// name the corners ul, ur, or, ol: an older corner order); with today's order LL, LR, UR, UL
+// (TagReconstructor.h:47-50) the tag frame is (x, y, z), and y is re-orthogonalised (z cross x) so that the matrix is
+// a rotation before it becomes the quaternion the current ReconstructedTag stores.
+static void points_to_tag(const double* pts, double* qt)
+{
+    double ex[3], ey[3], ez[3];
+    for (int a = 0; a < 3; ++a) {
+        ex[a] = pts[3 + a] - pts[a];
+        ey[a] = pts[9 + a] - pts[a];
+    }
+    auto normalise = [](double* v) {
+        const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (n > 0.0)
+            for (int a = 0; a < 3; ++a)
+                v[a] /= n;
+    };
+    normalise(ex);
+    normalise(ey);
+    ez[0] = ex[1] * ey[2] - ex[2] * ey[1];
+    ez[1] = ex[2] * ey[0] - ex[0] * ey[2];
+    ez[2] = ex[0] * ey[1] - ex[1] * ey[0];
+    normalise(ez);
+    ey[0] = ez[1] * ex[2] - ez[2] * ex[1];
+    ey[1] = ez[2] * ex[0] - ez[0] * ex[2];
+    ey[2] = ez[0] * ex[1] - ez[1] * ex[0];
+    const double m00 = ex[0], m01 = ey[0], m02 = ez[0], m10 = ex[1], m11 = ey[1], m12 = ez[1], m20 = ex[2], m21 = ey[2],
+                 m22 = ez[2];
+    // Eigen::Quaterniond(Matrix3d)
+    double q[4];
+    const double tr = m00 + m11 + m22;
+    if (tr > 0.0) {
+        double t = sqrt(tr + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (m21 - m12) * t;
+        q[2] = (m02 - m20) * t;
+        q[3] = (m10 - m01) * t;
+    } else {
+        const double m[3][3] = { { m00, m01, m02 }, { m10, m11, m12 }, { m20, m21, m22 } };
+        int i = 0;
+        if (m[1][1] > m[0][0])
+            i = 1;
+        if (m[2][2] > m[i][i])
+            i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double t = sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+        q[1 + i] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[k][j] - m[j][k]) * t;
+        q[1 + j] = (m[j][i] + m[i][j]) * t;
+        q[1 + k] = (m[k][i] + m[i][k]) * t;
+    }
+    for (int a = 0; a < 4; ++a)
+        qt[a] = q[a];
+    for (int a = 0; a < 3; ++a)
+        qt[4 + a] = (pts[a] + pts[3 + a] + pts[6 + a] + pts[9 + a]) / 4.0;
+}
+
+// caller's tag poses -> the device's point pairs [2 * n_tags][7] (slot 6 unused)
+static std::vector<double> pairs_from_tags(const double* tag_qt, const double* tag_wh, int n_tags)
+{
+    std::vector<double> pairs((size_t)14 * n_tags, 0.0);
+    for (int t = 0; t < n_tags; ++t) {
+        double pts[12];
+        tag_to_points(tag_qt + 7 * (size_t)t, tag_wh + 2 * (size_t)t, pts);
+        for (int k = 0; k < 6; ++k) {
+            pairs[(size_t)14 * t + k] = pts[k];
+            pairs[(size_t)14 * t + 7 + k] = pts[6 + k];
+        }
+    }
+    return pairs;
+}
+
 static int do_allreduce(Engine& e, double* buf, size_t count)
 {
     if (!e.multi)
@@ -661,6 +754,48 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         set_error("fixed_tag out of range");
         return VMM_BA_ERR_ARGUMENT;
     }
+    if (co.landmarks != VMM_BA_LANDMARK_TAG_POSES && co.landmarks != VMM_BA_LANDMARK_POINTS) {
+        set_error("create_options.landmarks must be VMM_BA_LANDMARK_TAG_POSES or VMM_BA_LANDMARK_POINTS");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    if (co.landmarks == VMM_BA_LANDMARK_POINTS && co.precision != VMM_BA_PRECISION_F64) {
+        set_error("point landmarks run in f64 only");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    // Point landmarks (doBundleAdjustment_points, src/TagReconstructor.cpp:457-644): every tag becomes its four world
+    // corners (:483-491), kept as two 6-dof blocks of two points each; every tag observation becomes the two corner-pair
+    // observations of those blocks (:549-560).  From here on `p` is that expanded problem.
+    const vmm_ba_problem* const user = p;
+    vmm_ba_problem expanded;
+    std::vector<double> x_tag, x_wh, x_px;
+    std::vector<int32_t> x_cam, x_tagidx;
+    if (co.landmarks == VMM_BA_LANDMARK_POINTS) {
+        if (p->n_obs >= (int64_t)1 << 30 || p->n_tags >= 1 << 30) {
+            set_error("problem too large for point landmarks");
+            return VMM_BA_ERR_ARGUMENT;
+        }
+        x_tag = pairs_from_tags(p->tag_qt, p->tag_wh, p->n_tags);
+        x_wh.assign((size_t)4 * p->n_tags, 0.0);
+        x_cam.resize((size_t)2 * p->n_obs);
+        x_tagidx.resize((size_t)2 * p->n_obs);
+        x_px.assign((size_t)16 * p->n_obs, 0.0);
+        for (int64_t i = 0; i < p->n_obs; ++i)
+            for (int h2 = 0; h2 < 2; ++h2) {
+                x_cam[(size_t)2 * i + h2] = p->obs_cam[i];
+                x_tagidx[(size_t)2 * i + h2] = 2 * p->obs_tag[i] + h2;
+                for (int k = 0; k < 4; ++k)
+                    x_px[(size_t)8 * (2 * i + h2) + k] = p->obs_px[8 * i + 4 * h2 + k];
+            }
+        expanded = *p;
+        expanded.n_tags = 2 * p->n_tags;
+        expanded.tag_qt = x_tag.data();
+        expanded.tag_wh = x_wh.data();
+        expanded.n_obs = 2 * p->n_obs;
+        expanded.obs_cam = x_cam.data();
+        expanded.obs_tag = x_tagidx.data();
+        expanded.obs_px = x_px.data();
+        p = &expanded;
+    }
     if (co.precision != VMM_BA_PRECISION_F64 && co.precision != VMM_BA_PRECISION_F32_ACCUM) {
         set_error("create_options.precision must be VMM_BA_PRECISION_F64 or VMM_BA_PRECISION_F32_ACCUM");
         return VMM_BA_ERR_ARGUMENT;
@@ -730,8 +865,14 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.K.k1 = p->dist[0]; e.K.k2 = p->dist[1]; e.K.p1 = p->dist[2]; e.K.p2 = p->dist[3]; e.K.k3 = p->dist[4];
     e.n_cams = p->n_cams;
     e.n_tags = p->n_tags;
-    e.fixed_tag = p->fixed_tag;
+    e.fixed_tag = user->fixed_tag;
     e.n_obs = p->n_obs;
+    e.points = co.landmarks == VMM_BA_LANDMARK_POINTS;
+    e.n_tags_user = user->n_tags;
+    e.n_obs_user = user->n_obs;
+    if (e.points) {
+        std::vector<double>(user->tag_wh, user->tag_wh + 2 * (size_t)user->n_tags).swap(e.user_tag_wh);
+    }
     int elim = co.elimination;
     if (elim == VMM_BA_ELIM_AUTO)
         elim = (p->n_cams >= p->n_tags) ? VMM_BA_ELIM_CAMERAS : VMM_BA_ELIM_TAGS;
@@ -931,9 +1072,37 @@ int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt
     HIP_TRY(hipSetDevice(e.device));
     if (cam_qt)
         HIP_TRY(hipMemcpyAsync(e.cam_qt, cam_qt, sizeof(double) * 7 * e.n_cams, hipMemcpyHostToDevice, e.stream));
+    std::vector<double> pairs;
+    if (tag_qt && e.points) {   // tag poses -> their corners, as at create
+        pairs = pairs_from_tags(tag_qt, e.user_tag_wh.data(), e.n_tags_user);
+        tag_qt = pairs.data();
+    }
     if (tag_qt)
         HIP_TRY(hipMemcpyAsync(e.tag_qt, tag_qt, sizeof(double) * 7 * e.n_tags, hipMemcpyHostToDevice, e.stream));
     HIP_TRY(hipStreamSynchronize(e.stream));
+    return VMM_BA_OK;
+}
+
+int vmm_ba_get_points(vmm_ba_handle h, double* points)
+{
+    if (!h || !points) {
+        set_error("null argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (!e.points) {
+        set_error("vmm_ba_get_points: the handle was not created with VMM_BA_LANDMARK_POINTS");
+        return VMM_BA_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(e.device));
+    std::vector<double> pairs((size_t)7 * e.n_tags);
+    HIP_TRY(hipMemcpyAsync(pairs.data(), e.tag_qt, sizeof(double) * pairs.size(), hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    for (int t = 0; t < e.n_tags_user; ++t)
+        for (int k = 0; k < 6; ++k) {
+            points[(size_t)12 * t + k] = pairs[(size_t)14 * t + k];
+            points[(size_t)12 * t + 6 + k] = pairs[(size_t)14 * t + 7 + k];
+        }
     return VMM_BA_OK;
 }
 
@@ -947,6 +1116,15 @@ int vmm_ba_get_state(vmm_ba_handle h, double* cam_qt, double* tag_qt)
     HIP_TRY(hipSetDevice(e.device));
     if (cam_qt)
         HIP_TRY(hipMemcpyAsync(cam_qt, e.cam_qt, sizeof(double) * 7 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
+    if (tag_qt && e.points) {   // tag poses rebuilt from the optimised corners (src/TagReconstructor.cpp:608-639)
+        std::vector<double> pts((size_t)12 * e.n_tags_user);
+        HIP_TRY(hipStreamSynchronize(e.stream));
+        int rc;
+        if ((rc = vmm_ba_get_points(h, pts.data()))) return rc;
+        for (int t = 0; t < e.n_tags_user; ++t)
+            points_to_tag(pts.data() + (size_t)12 * t, tag_qt + (size_t)7 * t);
+        return VMM_BA_OK;
+    }
     if (tag_qt)
         HIP_TRY(hipMemcpyAsync(tag_qt, e.tag_qt, sizeof(double) * 7 * e.n_tags, hipMemcpyDeviceToHost, e.stream));
     HIP_TRY(hipStreamSynchronize(e.stream));
@@ -1067,8 +1245,9 @@ int vmm_ba_set_observation_mask(vmm_ba_handle h, const uint8_t* mask)
         return VMM_BA_OK;
     if (mask) {
         std::vector<uint8_t> m((size_t)e.n_obs);
+        const int rep = e.points ? 2 : 1;   // a tag observation is two point-pair observations
         for (int64_t i = 0; i < e.n_obs; ++i)
-            m[(size_t)i] = mask[i] ? 1 : 0;
+            m[(size_t)i] = mask[i / rep] ? 1 : 0;
         HIP_TRY(hipMemcpyAsync(e.obs_mask, m.data(), m.size(), hipMemcpyHostToDevice, e.stream));
         HIP_TRY(hipStreamSynchronize(e.stream));   // the staging vector goes out of scope
     } else {
@@ -1085,6 +1264,10 @@ int vmm_ba_reprojection_stats(vmm_ba_handle h, double* per_cam_mean, double* per
         return VMM_BA_ERR_ARGUMENT;
     }
     Engine& e = *reinterpret_cast<Engine*>(h);
+    if (e.points) {
+        set_error("reprojection_stats works on tag poses: read them with vmm_ba_get_state and use a tag-pose handle");
+        return VMM_BA_ERR_STATE;
+    }
     HIP_TRY(hipSetDevice(e.device));
     const int n_pose = e.n_cams + e.n_tags;
     if (per_corner && e.n_obs > 0 && !e.stats_corner) {
@@ -1128,8 +1311,8 @@ int vmm_ba_tag_translation_covariance(vmm_ba_handle h, int robustify, double hub
         return VMM_BA_ERR_ARGUMENT;
     }
     Engine& e = *reinterpret_cast<Engine*>(h);
-    if (e.multi) {
-        set_error("tag_translation_covariance is a single-GPU entry point");
+    if (e.multi || e.points) {
+        set_error("tag_translation_covariance needs a single-GPU handle with tag-pose landmarks");
         return VMM_BA_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(e.device));
@@ -1225,6 +1408,10 @@ int vmm_ba_eval_blocks(vmm_ba_handle h, int robustify, double huber_a, double* c
         return VMM_BA_ERR_ARGUMENT;
     }
     Engine& e = *reinterpret_cast<Engine*>(h);
+    if (e.points && (U || W || g_tag)) {
+        set_error("eval_blocks: with point landmarks only cost, V and g_cam are in the caller's index space");
+        return VMM_BA_ERR_STATE;
+    }
     HIP_TRY(hipSetDevice(e.device));
     launch_eval_passes(e, false, robustify, huber_a, false);
     HIP_TRY(hipGetLastError());

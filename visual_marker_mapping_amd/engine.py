@@ -8,8 +8,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (CONVERGENCE, ELIM_AUTO, ELIM_CAMERAS, ELIM_TAGS, FAILURE, NO_CONVERGENCE,  # noqa: F401
-                   PRECISION_F32_ACCUM, PRECISION_F64)
+from ._lib import (CONVERGENCE, ELIM_AUTO, ELIM_CAMERAS, ELIM_TAGS, FAILURE, LANDMARK_POINTS,  # noqa: F401
+                   LANDMARK_TAG_POSES, NO_CONVERGENCE, PRECISION_F32_ACCUM, PRECISION_F64)
 
 
 def _ptr(a):
@@ -28,7 +28,8 @@ def default_options(**kw):
 
 class BundleAdjuster:
     def __init__(self, intr, dist, cam_qt, tag_qt, tag_wh, fixed_tag, obs_cam, obs_tag, obs_px,
-                 device=0, elimination=ELIM_AUTO, rank=0, world_size=1, precision=PRECISION_F64):
+                 device=0, elimination=ELIM_AUTO, rank=0, world_size=1, precision=PRECISION_F64,
+                 landmarks=LANDMARK_TAG_POSES):
         L = _lib.lib()
         self._h = C.c_void_p()
         self.intr = np.ascontiguousarray(intr, np.float64).reshape(4)
@@ -57,6 +58,8 @@ class BundleAdjuster:
         L.vmm_ba_default_create_options(C.byref(co))
         co.device, co.elimination, co.rank, co.world_size = device, elimination, rank, world_size
         co.precision = int(precision)
+        co.landmarks = int(landmarks)
+        self.landmarks = int(landmarks)
         _lib.check(L.vmm_ba_create(C.byref(p), C.byref(co), C.byref(self._h)))
         self._allreduce_cb = None
 
@@ -93,6 +96,13 @@ class BundleAdjuster:
         cam, tag = np.zeros((self.n_cams, 7)), np.zeros((self.n_tags, 7))
         _lib.check(_lib.lib().vmm_ba_get_state(self._h, _ptr(cam), _ptr(tag)))
         return cam, tag
+
+    def get_points(self):
+        """LANDMARK_POINTS handles: (n_tags, 4, 3) world corners LL, LR, UR, UL -- the parameter blocks of
+        doBundleAdjustment_points (/root/reference/src/TagReconstructor.cpp:485-492)."""
+        pts = np.zeros((self.n_tags, 4, 3))
+        _lib.check(_lib.lib().vmm_ba_get_points(self._h, _ptr(pts)))
+        return pts
 
     def set_allreduce(self, fn):
         """fn(device_ptr:int, count:int, hip_stream:int) -> None; sum-all-reduce in place."""
@@ -159,6 +169,8 @@ class BundleAdjuster:
         V, U = np.zeros((self.n_cams, 6, 6)), np.zeros((self.n_tags, 6, 6))
         W = np.zeros((self.n_obs, 6, 6)) if want_W else None
         gc, gt = np.zeros((self.n_cams, 6)), np.zeros((self.n_tags, 6))
+        if self.landmarks == LANDMARK_POINTS:   # the landmark-side blocks live in the library's point-pair index space
+            U = W = gt = None
         c = C.c_double(0)
         _lib.check(_lib.lib().vmm_ba_eval_blocks(self._h, int(bool(robustify)), float(huber_a), C.byref(c),
                                                  _ptr(V), _ptr(U), _ptr(W), _ptr(gc), _ptr(gt)))

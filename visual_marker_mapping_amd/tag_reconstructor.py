@@ -515,6 +515,42 @@ class TagReconstructor:
             avg_diag /= len(p["tag_ids"])
             print("Marker Position RMS = %.6g" % np.linalg.norm(np.sqrt(avg_diag)))
 
+    def doBundleAdjustment_points(self, maxNumIterations, ceresThreads=1, printSummary=False,
+                                  elimination=_engine.ELIM_AUTO):
+        """src/TagReconstructor.cpp:457-644 (`#if 0` in the reference): the same bundle adjustment with every
+        reconstructed tag replaced by its four world corners as free 3-D points (OpenCVReprojectionError,
+        TagReconstructionCostFunction.h:9-84; 3x3 landmark blocks, SPARSE_SCHUR ordering :492,534-535), the origin
+        tag's corners constant (:494-497), no loss (:556).  Cameras are written back as at :583-605, tag poses are
+        rebuilt from the optimised corners as at :608-639 (with today's corner order, see vmm_ba.h); the corners
+        themselves are kept in self.lastPoints (tag id -> 4 x 3)."""
+        p = self._pack(for_ba=True)
+        if len(p["cam_ids"]) == 0 or len(p["tag_ids"]) == 0 or p["n_active"] == 0:
+            print("Solution %d" % _engine.CONVERGENCE)
+            self.lastSummary = {"termination_type": _engine.CONVERGENCE, "iterations": 1}
+            return
+        ba = self._engine_for(p, elimination=elimination, landmarks=_engine.LANDMARK_POINTS)
+        try:
+            opts = _engine.default_options(max_num_iterations=int(maxNumIterations), robustify=0,
+                                           num_threads=int(ceresThreads))
+            summary = ba.solve(opts, trace_capacity=int(maxNumIterations) + 2 if printSummary else 0)
+            cam, tag = ba.get_state()
+            pts = ba.get_points()
+        except Exception:
+            self._drop_cached()
+            raise
+        for k, cid in zip(p["cam_rows"], p["cam_ids"]):
+            self.reconstructedCameras[cid].q = cam[k, :4].copy()
+            self.reconstructedCameras[cid].t = cam[k, 4:].copy()
+        self.lastPoints = {}
+        for k, tid in zip(p["tag_rows"], p["tag_ids"]):
+            self.reconstructedTags[tid].q = tag[k, :4].copy()
+            self.reconstructedTags[tid].t = tag[k, 4:].copy()
+            self.lastPoints[tid] = pts[k].copy()
+        self.lastSummary = summary
+        print("Solution %d" % summary["termination_type"])                                   # :579
+        print("Cost: initial %.6e final %.6e; iterations %d; time in solver %.4f s" % (     # :580-581 (FullReport)
+            summary["initial_cost"], summary["final_cost"], summary["iterations"], summary["time_solve_s"]))
+
     # -- reprojection statistics + pruning (src/TagReconstructor.cpp:340-455, 786-816) --
     def _stats(self, per_corner):
         p = self._pack(for_ba=False)
