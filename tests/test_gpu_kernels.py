@@ -216,3 +216,34 @@ def test_bad_indices_are_rejected(eng):
     with pytest.raises(_lib.VmmBaError):
         eng.BundleAdjuster([1, 1, 0, 0], [0] * 5, [[1, 0, 0, 0, 0, 0, 1]], [[1, 0, 0, 0, 0, 0, 0]], [[0.1, 0.1]],
                            0, [3], [0], [[0] * 8])
+
+
+def test_large_cholesky_on_the_stamps_build():
+    """The diagnostic build (-DVMM_STAMPS) changes the register pressure inside the looping trailing-update workgroups
+    whose loads are issued as inline asm: the same n = 2048 solve must come out right there too (a subprocess, because
+    the library path is fixed at import)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "visual_marker_mapping_amd", "libvmm_ba_stamps.so")
+    assert os.path.exists(lib), "build() makes it (make -C visual_marker_mapping_amd/csrc stamps)"
+    code = """
+import numpy as np
+from visual_marker_mapping_amd import engine as eng
+rng = np.random.default_rng(2048)
+n = 2048
+B = rng.standard_normal((n, n // 4))
+A = B @ B.T + np.diag(rng.uniform(1.0, 2.0, n)) * n
+b = rng.standard_normal(n)
+x, info = eng.dense_spd_solve(A, b)
+ref = np.linalg.solve(A, b)
+assert info == 0 and np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max(), (info, np.abs(x - ref).max())
+x2, _ = eng.dense_spd_solve(A, b)
+assert np.array_equal(x, x2)
+print("stamps build ok")
+"""
+    env = dict(os.environ, VMM_BA_LIB=lib, PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         universal_newlines=True, timeout=300)
+    assert out.returncode == 0 and "stamps build ok" in out.stdout, out.stdout

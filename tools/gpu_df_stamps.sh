@@ -20,7 +20,8 @@ for rep in range(3):
     print("rep", rep, "err", np.abs(x - np.linalg.solve(A, b)).max())
     for j in range(19):
         r = (s[j, :10] - t0) / 100.0   # us
-        print("j=%2d start %7.2f consumed %7.2f rounds %s" % (j, r[0], r[1], " ".join("%7.2f" % v for v in r[2:10])))
+        d = (s[j, 12:14] - t0) / 100.0
+        print("j=%2d start %7.2f [slice 6 seen %7.2f slice 7 seen %7.2f] consumed %7.2f rounds %s" % (j, r[0], d[0], d[1], r[1], " ".join("%7.2f" % v for v in r[2:10])))
     j = 5
     p = s[j, 40:46] - s[j, 40]
     wk = s[j, 48:55] - s[j, 48]

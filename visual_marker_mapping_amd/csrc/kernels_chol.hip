@@ -1162,8 +1162,17 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
     __syncthreads();   // phase 1 done: the pivot block is in pdc
     if (J0 == 16) DF_CY(41);
     Piv8 p;
-    if (active)
+    if (active) {
         chol8(pdc + J0 * kPs, p);
+        // the factor is complete BEFORE the barrier: left alone, the compiler sinks its arithmetic behind the barrier
+        // and the 8x8 Cholesky no longer overlaps with the workers' phase 2 (measured with the stamps build)
+#pragma unroll
+        for (int k = 0; k < 36; ++k)
+            asm volatile("" : "+v"(p.l[k]));
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            asm volatile("" : "+v"(p.inv[k]));
+    }
     if (J0 == 16) DF_CY(42);
     __syncthreads();   // phase 2 done: all rows of columns J0..J0+7 are in pdc / ptc
     if (J0 == 16) DF_CY(43);
@@ -1249,6 +1258,10 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
             const int k = it >> 3, r = it & 7;
             if (sweeper) {
                 const bool got = wait_slice(sm.at(k, my_rb, r), lane, epoch, a.abort_word, k == j - 1, g);
+#ifdef VMM_STAMPS
+                if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 2)
+                    g_df_stamps[m.stamp_j][12 + (it - (n_it - 2))] = __builtin_amdgcn_s_memrealtime();
+#endif
                 double* X = m.Xs + (it & 1) * 2 * kDfXs + (w == 0 ? 0 : kDfXs);
                 const double nan = __longlong_as_double(0x7ff8000000000000ll);
 #pragma unroll
@@ -1281,22 +1294,29 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
 }
 
 // ---- a worker wave's program ----
-template <int WK, int J0, bool HAS_T>
-__device__ __forceinline__ void worker_round(const int lane, double4_t (&acc)[13], const Lds& m)
+// SLICE (round 0 of a block column > 0 only): the "previous round" is the last slice of the previous panel, staged
+// at XJ / XR and not applied yet -- its update of the first pivot tile column comes first like any round's, so the
+// pivot waves start on the panel 16 MFMAs after the slice has arrived instead of 26 + a round.
+template <int WK, int J0, bool HAS_T, bool SLICE = false>
+__device__ __forceinline__ void worker_round(const int lane, double4_t (&acc)[13], const Lds& m, const double* XJ = nullptr,
+                                             const double* XR = nullptr)
 {
+    static_assert(!SLICE || J0 == 0, "only the first round takes a slice");
     const int fr = lane & 15, fk = lane >> 4;
     double* pdc = m.Pd + ((J0 >> 3) & 1) * 64 * kPs;
     double* ptc = m.Pt + ((J0 >> 3) & 1) * 64 * kPs;
     const double* pdp = m.Pd + (((J0 >> 3) & 1) ^ 1) * 64 * kPs;
     const double* ptp = m.Pt + (((J0 >> 3) & 1) ^ 1) * 64 * kPs;
-    constexpr bool UPD = J0 > 0;
+    constexpr bool UPD = J0 > 0 || SLICE;
 #ifdef VMM_STAMPS
     const bool stamp_on = m.stamp_j >= 0 && WK == 0;
     const int stamp_j = m.stamp_j;
 #endif
     Ops o[2];
     if (J0 == 16) DF_CY(48);
-    if (UPD)
+    if (SLICE)
+        load_ops_slice<WK, HAS_T>(XJ, XR, fr, fk, o);
+    else if (UPD)
         load_ops_panel<WK, HAS_T>(pdp, ptp, J0, fr, fk, o);
     worker_phase<WK, HAS_T, J0, 1, UPD>(acc, o, pdc, ptc, fr, fk, Seq13{});
     if (J0 == 16) DF_CY(49);
@@ -1340,7 +1360,7 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
         }
     }, Seq13{});
     const int n_it = 8 * j;
-    for (int it = 0; it < n_it; ++it) {
+    for (int it = 0; it + 1 < n_it; ++it) {
         const double* XJ = m.Xs + (it & 1) * 2 * kDfXs;
         const double* XR = XJ + kDfXs;
         __syncthreads();
@@ -1354,7 +1374,13 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
             }, Seq13{});
         }
     }
-    worker_round<WK, 0, HAS_T>(lane, acc, m);
+    if (n_it > 0) {
+        const double* XJ = m.Xs + ((n_it - 1) & 1) * 2 * kDfXs;
+        __syncthreads();   // the last slice is staged
+        worker_round<WK, 0, HAS_T, true>(lane, acc, m, XJ, XJ + kDfXs);
+    } else {
+        worker_round<WK, 0, HAS_T>(lane, acc, m);
+    }
     worker_round<WK, 8, HAS_T>(lane, acc, m);
     worker_round<WK, 16, HAS_T>(lane, acc, m);
     worker_round<WK, 24, HAS_T>(lane, acc, m);
