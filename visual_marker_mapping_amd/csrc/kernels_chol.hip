@@ -89,6 +89,10 @@ struct Piv8 {
 };
 
 // Cholesky of the symmetric 8x8 block at D (LDS, row stride kPs, lower triangle), in registers.
+// Right-looking: as soon as column j is scaled, its outer product is subtracted from the columns to its right, so
+// the NEXT pivot depends on one multiply and one fused multiply-add behind the reciprocal square root instead of
+// on a j-deep chain of dependent FMAs (the left-looking form cost ~143 cycles per pivot, this one ~100); the other
+// updates are independent and fill the issue slots the chain leaves free.
 __device__ __forceinline__ void chol8(const double* __restrict__ D, Piv8& p)
 {
 #pragma unroll
@@ -99,23 +103,34 @@ __device__ __forceinline__ void chol8(const double* __restrict__ D, Piv8& p)
     p.ok = true;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        double t = p.l[tri8(j, j)];
-#pragma unroll
-        for (int k = 0; k < j; ++k)
-            t -= p.l[tri8(j, k)] * p.l[tri8(j, k)];
+        const double t = p.l[tri8(j, j)];
         bool okj = true;
         const double inv = safe_rsqrt(t, okj);
         p.ok = p.ok && okj;
         p.inv[j] = inv;
         p.l[tri8(j, j)] = t * inv;
 #pragma unroll
-        for (int i = j + 1; i < 8; ++i) {
-            double v = p.l[tri8(i, j)];
+        for (int i = j + 1; i < 8; ++i)
+            p.l[tri8(i, j)] *= inv;
+        // the next pivot's diagonal first
 #pragma unroll
-            for (int k = 0; k < j; ++k)
-                v -= p.l[tri8(i, k)] * p.l[tri8(j, k)];
-            p.l[tri8(i, j)] = v * inv;
-        }
+        for (int c = j + 1; c < 8; ++c)
+#pragma unroll
+            for (int i = c; i < 8; ++i)
+                p.l[tri8(i, c)] = fma(-p.l[tri8(i, j)], p.l[tri8(c, j)], p.l[tri8(i, c)]);
+    }
+}
+
+// x <- x L8^{-T} (a row of eight columns scaled by the pivot block's factor), right-looking for the same reason:
+// every step is one multiply behind the previous step's update instead of a q-deep chain.
+__device__ __forceinline__ void scale8(double (&x)[8], const Piv8& p)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        x[q] *= p.inv[q];
+#pragma unroll
+        for (int c = q + 1; c < 8; ++c)
+            x[c] = fma(-x[q], p.l[tri8(c, q)], x[c]);
     }
 }
 
@@ -156,15 +171,7 @@ __device__ __forceinline__ void panel_round(const int w, const int lane,
             x[q] = row[q];
         Piv8 p;
         chol8(pd + J0 * kPs, p);
-        // x = a L8^{-T}
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            double v = x[q];
-#pragma unroll
-            for (int k = 0; k < q; ++k)
-                v -= x[k] * p.l[tri8(q, k)];
-            x[q] = v * p.inv[q];
-        }
+        scale8(x, p);   // x = a L8^{-T}
         if (w == 0) {
             ok = ok && p.ok;
             const int r = lane - J0;
@@ -1182,50 +1189,8 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             x[q] = row[q];
-        // x = a L8^{-T}
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            double v = x[q];
-#pragma unroll
-            for (int k = 0; k < q; ++k)
-                v -= x[k] * p.l[tri8(q, k)];
-            x[q] = v * p.inv[q];
-        }
-        if (w == 0) {
-            ok = ok && p.ok;
-            const int r = lane - J0;
-            const bool below = r >= kPw, above = r < 0;
-            if (below) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    row[q] = x[q];
-            }
-            if (!HAS_T) {
-                // keep L^T for the write-back: x below the pivot block, the factor inside, zero above
-                double* At = m.RA;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    double inside = 0.0;
-#pragma unroll
-                    for (int rr = q; rr < 8; ++rr)
-                        inside = (r == rr) ? p.l[tri8(rr, q)] : inside;
-                    At[(J0 + q) * kLdT + lane] = below ? x[q] : (above ? 0.0 : inside);
-                }
-                if (r >= 0 && r < kPw) {
-                    double iv = 0.0;
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr)
-                        iv = (r == rr) ? p.inv[rr] : iv;
-                    m.invd[lane] = iv;
-                }
-            }
-        } else {
-            double* rr = m.RA + lane * kLd + J0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                row[q] = x[q];
-                rr[q] = x[q];
-            }
+        scale8(x, p);   // x = a L8^{-T}
+        auto publish = [&]() {
             const unsigned long long tag = (unsigned long long)epoch << 32;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -1235,12 +1200,57 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
                 __hip_atomic_store(gs + 512 + q * 64 + lane, tag | (bits >> 32), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
+        };
+        if (w == 1) {
+            // the rows below leave for the other workgroups first (the longest latency of the round; holding them
+            // back behind the barrier in all rounds but the last was measured slower) ...
+            publish();
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                row[q] = x[q];
+        } else {
+            ok = ok && p.ok;
+            if (lane - J0 >= kPw) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    row[q] = x[q];
+            }
         }
+        if (J0 == 16) DF_CY(44);
+        __syncthreads();   // phase 3 done: the scaled columns are in pdc / ptc
+        if (J0 == 16) DF_CY(45);
+        DF_RT(2 + (J0 >> 3));
+        // ... what only this workgroup's final write-back needs is stored behind the barrier, beside the workers'
+        // phase 1 of the next round
+        if (w == 1) {
+            double* rr = m.RA + lane * kLd + J0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                rr[q] = x[q];
+        } else if (!HAS_T) {
+            // keep L^T for the write-back: x below the pivot block, the factor inside, zero above
+            const int r = lane - J0;
+            const bool below = r >= kPw, above = r < 0;
+            double* At = m.RA;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                double inside = 0.0;
+#pragma unroll
+                for (int rr = q; rr < 8; ++rr)
+                    inside = (r == rr) ? p.l[tri8(rr, q)] : inside;
+                At[(J0 + q) * kLdT + lane] = below ? x[q] : (above ? 0.0 : inside);
+            }
+            if (r >= 0 && r < kPw) {
+                double iv = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)
+                    iv = (r == rr) ? p.inv[rr] : iv;
+                m.invd[lane] = iv;
+            }
+        }
+    } else {
+        __syncthreads();   // phase 3 done (idle pivot wave of the diagonal-only role)
     }
-    if (J0 == 16) DF_CY(44);
-    __syncthreads();   // phase 3 done: the scaled columns are in pdc / ptc
-    if (J0 == 16) DF_CY(45);
-    DF_RT(2 + (J0 >> 3));
 }
 
 template <bool HAS_T>
@@ -1432,7 +1442,8 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
         worker_path<0, HAS_T>(a, lane, j, R, m);
     else
         worker_path<1, HAS_T>(a, lane, j, R, m);
-    // results for the kernels after this launch (the last barrier of the last round orders the LDS tiles)
+    __syncthreads();   // the pivot waves store their rows of the result tile behind the last round's barrier
+    // results for the kernels after this launch
     if (!HAS_T) {
         if (tid < 64)
             a.dinv[K0 + tid] = m.invd[tid];
