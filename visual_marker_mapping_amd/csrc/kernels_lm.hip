@@ -280,95 +280,17 @@ __global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, c
     }
 }
 
-// Back-substitution of the eliminated family: y_e = L_e^{-T} (z_e - Z_e y_f), delta_e = -s_e y_e, and
-// the pose's share of the model-cost cross term sum_obs delta_e^T W_ef delta_f.  With
-// W_ef = s_e^-1 L_e Z_ef s_f^-1 and delta = -s y that share is (L_e^T y_e)^T (Z_e y_f) = (z_e - a)^T a
-// for a = Z_e y_f, which this kernel has anyway: no second pass over the observations and W.
-// One wave per eliminated pose.
-__global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose,
-                                                 const int32_t* __restrict__ pose_task,
-                                                 const double* __restrict__ Z, int ldz, int n_red,
-                                                 const double* __restrict__ yf, const double* __restrict__ Le,
-                                                 const double* __restrict__ ze, const double* __restrict__ scale,
-                                                 double* __restrict__ step_comm, double* __restrict__ part_cross)
+// One pose's share of TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost (first half): the unscaled tangent
+// step d, the candidate x+ = Plus(x, d), and the pose's terms of the model cost and of the step / parameter norms:
+// pose_part[p] = { d.g, d^T H d, |x - x+|^2, |x+|^2, non-finite flag } (the norms only for active poses).
+__device__ __forceinline__ void candidate_for_pose(const PoseViews& pv, const int p, const double (&d)[6],
+                                                   double* __restrict__ delta, const double* __restrict__ H,
+                                                   const double* __restrict__ g, const int32_t* __restrict__ active,
+                                                   double* __restrict__ pose_part)
 {
-    if (ctl->done)
-        return;
-    phase_stamp(ctl, 4);
-    const int e = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
-    if (e >= n_e)
-        return;
-    const bool owned = pose_task[e + 1] > pose_task[e];
-    if (!owned || ctl->lin_fail) {
-        if (lane < 6)
-            step_comm[6 * (int64_t)e + lane] = 0.0;
-        if (lane == 0)
-            part_cross[e] = 0.0;
-        return;
-    }
-    double acc[6] = { 0, 0, 0, 0, 0, 0 };
-    const double* zr = Z + (int64_t)(6 * e) * ldz;
-    for (int c = lane; c < n_red; c += 64) {
-        const double yv = yf[c];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            acc[i] += zr[(int64_t)i * ldz + c] * yv;
-    }
-    double v[6];
-    double cr = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double a = wave_sum(acc[i]);
-        v[i] = ze[6 * (int64_t)e + i] - a;
-        cr += v[i] * a;
-    }
-    const double* L = Le + 36 * (int64_t)e;
-#pragma unroll
-    for (int i = 5; i >= 0; --i) {
-        double s = v[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; ++k)
-            s -= L[6 * k + i] * v[k];
-        v[i] = s / L[6 * i + i];
-    }
-    if (lane < 6) {
-        double out = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            out = (lane == i) ? -v[i] * scale[6 * (int64_t)(e_off_pose + e) + i] : out;
-        step_comm[6 * (int64_t)e + lane] = out;
-    }
-    if (lane == 0)
-        part_cross[e] = cr;
-}
-
-// delta (unscaled tangent step) for every pose, the candidate x+ = Plus(x, delta)
-// (TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost, first half) and this pose's terms of
-// the model cost and of the step/parameter norms: pose_part[p] = { delta.g, delta^T H delta,
-// |x - x+|^2, |x+|^2, non-finite flag } (the last two only for active poses).
-__global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_pose, int f_off_pose,
-                            const double* __restrict__ step_comm, const double* __restrict__ yf,
-                            const double* __restrict__ scale, double* __restrict__ delta,
-                            const double* __restrict__ H, const double* __restrict__ g,
-                            const int32_t* __restrict__ active, double* __restrict__ pose_part)
-{
-    if (ctl->done)
-        return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_pose = pv.n_cams + pv.n_tags;
-    if (p >= n_pose)
-        return;
-    const bool is_e = (p >= e_off_pose) && (p < e_off_pose + n_e);
-    double d[6];
     double bad = 0.0;
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
-        if (ctl->lin_fail)
-            d[k] = 0.0;
-        else if (is_e)
-            d[k] = step_comm[6 * (int64_t)(p - e_off_pose) + k];
-        else
-            d[k] = -yf[6 * (int64_t)(p - f_off_pose) + k] * scale[6 * (int64_t)p + k];
         delta[6 * (int64_t)p + k] = d[k];
         if (!isfinite(d[k]))
             bad = 1.0;
@@ -400,6 +322,127 @@ __global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_p
     o[2] = act ? sn : 0.0;
     o[3] = act ? xn : 0.0;
     o[4] = bad;
+}
+
+// Back-substitution of the eliminated family: y_e = L_e^{-T} (z_e - Z_e y_f), delta_e = -s_e y_e, and
+// the pose's share of the model-cost cross term sum_obs delta_e^T W_ef delta_f.  With
+// W_ef = s_e^-1 L_e Z_ef s_f^-1 and delta = -s y that share is (L_e^T y_e)^T (Z_e y_f) = (z_e - a)^T a
+// for a = Z_e y_f, which this kernel has anyway: no second pass over the observations and W.
+// One wave per eliminated pose.
+// FUSE (one GPU): the candidate of every pose is formed here too -- an eliminated pose's by lane 0 of its wave, the
+// kept poses' by one thread each in the workgroups behind the eliminated family's -- instead of in k_candidate.
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose,
+                                                 const int32_t* __restrict__ pose_task,
+                                                 const double* __restrict__ Z, int ldz, int n_red,
+                                                 const double* __restrict__ yf, const double* __restrict__ Le,
+                                                 const double* __restrict__ ze, const double* __restrict__ scale,
+                                                 double* __restrict__ step_comm, double* __restrict__ part_cross,
+                                                 PoseViews pv, int f_off_pose, int n_f, int nb_e,
+                                                 double* __restrict__ delta, const double* __restrict__ H,
+                                                 const double* __restrict__ g, const int32_t* __restrict__ active,
+                                                 double* __restrict__ pose_part)
+{
+    if (ctl->done)
+        return;
+    phase_stamp(ctl, 4);
+    const bool lin_fail = ctl->lin_fail != 0;
+    if (FUSE && (int)blockIdx.x >= nb_e) {
+        const int f = ((int)blockIdx.x - nb_e) * blockDim.x + threadIdx.x;
+        if (f >= n_f)
+            return;
+        const int p = f_off_pose + f;
+        double d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            d[k] = lin_fail ? 0.0 : -yf[6 * (int64_t)f + k] * scale[6 * (int64_t)p + k];
+        candidate_for_pose(pv, p, d, delta, H, g, active, pose_part);
+        return;
+    }
+    const int e = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (e >= n_e)
+        return;
+    const bool owned = pose_task[e + 1] > pose_task[e];
+    if (!owned || lin_fail) {
+        if (lane < 6)
+            step_comm[6 * (int64_t)e + lane] = 0.0;
+        if (lane == 0) {
+            part_cross[e] = 0.0;
+            if (FUSE) {
+                const double d[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+                candidate_for_pose(pv, e_off_pose + e, d, delta, H, g, active, pose_part);
+            }
+        }
+        return;
+    }
+    double acc[6] = { 0, 0, 0, 0, 0, 0 };
+    const double* zr = Z + (int64_t)(6 * e) * ldz;
+    for (int c = lane; c < n_red; c += 64) {
+        const double yv = yf[c];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            acc[i] += zr[(int64_t)i * ldz + c] * yv;
+    }
+    double v[6];
+    double cr = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double a = wave_sum(acc[i]);
+        v[i] = ze[6 * (int64_t)e + i] - a;
+        cr += v[i] * a;
+    }
+    const double* L = Le + 36 * (int64_t)e;
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = v[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k)
+            s -= L[6 * k + i] * v[k];
+        v[i] = s / L[6 * i + i];
+    }
+    double d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        d[i] = -v[i] * scale[6 * (int64_t)(e_off_pose + e) + i];
+    if (lane < 6) {
+        double out = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            out = (lane == i) ? d[i] : out;
+        step_comm[6 * (int64_t)e + lane] = out;
+    }
+    if (lane == 0) {
+        part_cross[e] = cr;
+        if (FUSE)
+            candidate_for_pose(pv, e_off_pose + e, d, delta, H, g, active, pose_part);
+    }
+}
+
+// World > 1 (the eliminated family's step is all-reduced first): the candidate of every pose in a launch of its own.
+__global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_pose, int f_off_pose,
+                            const double* __restrict__ step_comm, const double* __restrict__ yf,
+                            const double* __restrict__ scale, double* __restrict__ delta,
+                            const double* __restrict__ H, const double* __restrict__ g,
+                            const int32_t* __restrict__ active, double* __restrict__ pose_part)
+{
+    if (ctl->done)
+        return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_pose = pv.n_cams + pv.n_tags;
+    if (p >= n_pose)
+        return;
+    const bool is_e = (p >= e_off_pose) && (p < e_off_pose + n_e);
+    double d[6];
+    for (int k = 0; k < 6; ++k) {
+        if (ctl->lin_fail)
+            d[k] = 0.0;
+        else if (is_e)
+            d[k] = step_comm[6 * (int64_t)(p - e_off_pose) + k];
+        else
+            d[k] = -yf[6 * (int64_t)(p - f_off_pose) + k] * scale[6 * (int64_t)p + k];
+    }
+    candidate_for_pose(pv, p, d, delta, H, g, active, pose_part);
 }
 
 // Step validation, convergence tests, acceptance and radius update:
@@ -571,15 +614,28 @@ void launch_iter_begin(Engine& e, const double* src)
                        e.active, e.diag, e.D2, e.trace);
 }
 
+// One GPU: back-substitution and the candidates of all poses in one launch (launch_candidate is then a no-op).
 void launch_backsub(Engine& e)
 {
     const int e_off = e.elim_cams ? 0 : e.n_cams;
-    hipLaunchKernelGGL(k_backsub, dim3((e.n_e + 3) / 4), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
-                       e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross);
+    const int f_off = e.elim_cams ? e.n_cams : 0;
+    const int nb_e = (e.n_e + 3) / 4;
+    if (e.multi) {
+        hipLaunchKernelGGL((k_backsub<false>), dim3(nb_e), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
+                           e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off,
+                           e.n_f, nb_e, e.delta, e.H_cam, e.g_cam, e.active, e.pose_part);
+        return;
+    }
+    const int nb_f = (e.n_f + 255) / 256;
+    hipLaunchKernelGGL((k_backsub<true>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
+                       e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off, e.n_f,
+                       nb_e, e.delta, e.H_cam, e.g_cam, e.active, e.pose_part);
 }
 
 void launch_candidate(Engine& e)
 {
+    if (!e.multi)
+        return;   // formed by launch_backsub
     const int e_off = e.elim_cams ? 0 : e.n_cams;
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const int n_pose = e.n_cams + e.n_tags;
@@ -602,7 +658,8 @@ int preload_lm_kernels()
     hipFuncAttributes at;
     int bad = 0;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_iter_begin)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<false>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_candidate)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_decide)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_zero_unless_eval)) != hipSuccess;

@@ -44,73 +44,71 @@ __device__ __forceinline__ bool chol6(double* A)
     return ok;
 }
 
-// One thread per eliminated pose.
-__global__ void k_elim_factor(LmCtl* ctl, int n_e, int e_off_pose, const double* __restrict__ H_E,
-                              const double* __restrict__ g_E, const double* __restrict__ scale,
-                              const double* __restrict__ D2, double* __restrict__ Le,
-                              double* __restrict__ ze, const int32_t* __restrict__ pose_task,
-                              double* __restrict__ Z, int ldz, int zcol)
+// One thread per observation (E order): M_e = s_e H_e s_e + D_e^2 = L_e L_e^T, z_e = L_e^{-1} s_e g_e and the
+// observation's block Z_ef = L_e^{-1} (s_e W_ef s_f) into the dense Z.  Every observation of a pose factors that
+// pose's 6x6 block again (91 multiply-adds from L2-resident inputs against the 576 bytes of W and Z the thread
+// moves: cheaper than a launch of its own and the dependent kernel boundary behind it); the pose's first
+// observation stores L_e, z_e and the rhs column of Z.  A pose without observations owns no thread: nobody reads
+// its L_e, and its rows of Z (zero since vmm_ba_create) stay zero -- also what a rank needs for a pose whose
+// observations live on another rank.
+template <typename WT>
+__global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64_t n_pad,
+                                                 const int32_t* __restrict__ own,
+                                                 const int32_t* __restrict__ other,
+                                                 const WT* __restrict__ W,
+                                                 const double* __restrict__ H_E, const double* __restrict__ g_E,
+                                                 const double* __restrict__ D2,
+                                                 double* __restrict__ Le, double* __restrict__ ze,
+                                                 const double* __restrict__ scale, int e_off_pose,
+                                                 int f_off_pose, double* __restrict__ Z, int ldz, int zcol)
 {
     if (ctl->done)
         return;
     phase_stamp(ctl, 2);
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_e)
-        return;
-    const double* s = scale + 6 * (int64_t)(e_off_pose + e);
-    const double* d2 = D2 + 6 * (int64_t)(e_off_pose + e);
-    double M[36], v[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int b = 0; b < 6; ++b)
-            M[6 * a + b] = s[a] * H_E[36 * (int64_t)e + 6 * a + b] * s[b];
-        M[6 * a + a] += d2[a];
-        v[a] = s[a] * g_E[6 * (int64_t)e + a];
-    }
-    if (!chol6(M))
-        ctl->lin_fail = 1;
-    // z = L^{-1} v
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double t = v[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k)
-            t -= M[6 * i + k] * v[k];
-        v[i] = t / M[6 * i + i];
-    }
-#pragma unroll
-    for (int k = 0; k < 36; ++k)
-        Le[36 * (int64_t)e + k] = M[k];
-    // z column of the augmented Z (rhs of the eliminated block).  A pose is owned by the rank that
-    // holds its observations; elsewhere its rows of Z stay zero.
-    const bool owned = pose_task[e + 1] > pose_task[e];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        ze[6 * (int64_t)e + k] = v[k];
-        Z[(int64_t)(6 * e + k) * ldz + zcol] = owned ? v[k] : 0.0;
-    }
-}
-
-// One thread per observation (E order): Z block = L_e^{-1} (s_e W s_f) into the dense Z.
-template <typename WT>
-__global__ __launch_bounds__(256) void k_form_z(const LmCtl* ctl, int64_t n_obs, int64_t n_pad,
-                                                 const int32_t* __restrict__ own,
-                                                 const int32_t* __restrict__ other,
-                                                 const WT* __restrict__ W,
-                                                 const double* __restrict__ Le,
-                                                 const double* __restrict__ scale, int e_off_pose,
-                                                 int f_off_pose, double* __restrict__ Z, int ldz)
-{
-    if (ctl->done)
-        return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_obs)
         return;
     const int e = own[i], f = other[i];
     const double* se = scale + 6 * (int64_t)(e_off_pose + e);
     const double* sf = scale + 6 * (int64_t)(f_off_pose + f);
-    const double* L = Le + 36 * (int64_t)e;
+    double L[36];
+    {
+        const double* d2 = D2 + 6 * (int64_t)(e_off_pose + e);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                L[6 * a + b] = se[a] * H_E[36 * (int64_t)e + 6 * a + b] * se[b];
+            L[6 * a + a] += d2[a];
+        }
+    }
+    const bool ok = chol6(L);
+    const bool first = i == 0 || own[i - 1] != e;
+    if (first) {
+        if (!ok)
+            ctl->lin_fail = 1;
+        double v[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+            v[a] = se[a] * g_E[6 * (int64_t)e + a];
+        // z = L^{-1} v
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double t = v[r];
+#pragma unroll
+            for (int k = 0; k < r; ++k)
+                t -= L[6 * r + k] * v[k];
+            v[r] = t / L[6 * r + r];
+        }
+#pragma unroll
+        for (int k = 0; k < 36; ++k)
+            Le[36 * (int64_t)e + k] = L[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            ze[6 * (int64_t)e + k] = v[k];
+            Z[(int64_t)(6 * e + k) * ldz + zcol] = v[k];
+        }
+    }
     double X[36];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -385,16 +383,16 @@ void launch_elim(Engine& e)
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const double* H_E = e.elim_cams ? e.H_cam : e.H_tag;
     const double* g_E = e.elim_cams ? e.g_cam : e.g_tag;
-    hipLaunchKernelGGL(k_elim_factor, dim3((e.n_e + 63) / 64), dim3(64), 0, e.stream, e.ctl, e.n_e, e_off, H_E, g_E,
-                       e.scale, e.D2, e.Le, e.ze, e.ordE.pose_task, e.Z, e.ldz, e.n_pad);
     if (e.ordE.n > 0) {
         const dim3 grid((unsigned)((e.ordE.n + 255) / 256));
         if (e.f32_accum)
             hipLaunchKernelGGL((k_form_z<float>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,
-                               e.ordE.other, (const float*)e.Wf, e.Le, e.scale, e_off, f_off, e.Z, e.ldz);
+                               e.ordE.other, (const float*)e.Wf, H_E, g_E, (const double*)e.D2, e.Le, e.ze, e.scale, e_off,
+                               f_off, e.Z, e.ldz, e.n_pad);
         else
             hipLaunchKernelGGL((k_form_z<double>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,
-                               e.ordE.other, (const double*)e.W, e.Le, e.scale, e_off, f_off, e.Z, e.ldz);
+                               e.ordE.other, (const double*)e.W, H_E, g_E, (const double*)e.D2, e.Le, e.ze, e.scale, e_off,
+                               f_off, e.Z, e.ldz, e.n_pad);
     }
 }
 
@@ -480,7 +478,6 @@ int preload_schur_kernels()
 {
     hipFuncAttributes at;
     int bad = 0;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_elim_factor)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<double>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<float>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_syrk_streamk)) != hipSuccess;
