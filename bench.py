@@ -182,38 +182,47 @@ def main():
             scale = 1e-9 if v["unit"] == "GB/s" else 1e-12
             v["achieved"] = v["alg"] * scale / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
             v["frac"] = v["achieved"] / v["peak"]
-        # HBM bytes per launch from the PMC passes committed under profiles/ (tools/gpu_pmc.sh +
-        # tools/pmc_to_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction)
+        # HBM bytes per launch: NOT measured in this run -- read from the PMC passes committed under profiles/
+        # (tools/gpu_final.sh + tools/pmc_to_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+        # same command, gfx950 x2 read correction calibrated on k_cost's known 7.2 MB); traffic_source says so
         traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tname = "r02_pmc_traffic.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
         if a.config == 2 and a.visibility == 1.0 and os.path.exists(tpath):
             with open(tpath) as f:
                 bpl = json.load(f)["bytes_per_launch"]
-            nb = (n_red + 63) // 64
             traffic = {"eval_jacobian": bpl.get("eval_jacobian"), "eval_cost": bpl.get("eval_cost"),
                        "schur_syrk": bpl.get("schur_syrk"),
-                       "cholesky_solve": nb * bpl.get("chol_step", 0) + bpl.get("backsolve_chain", 0)}
+                       "cholesky_solve": (bpl.get("chol_dataflow") or 0) + (bpl.get("backsolve_chain") or 0)}
+        n_blk = (n_red + 63) // 64
+        dataflow = n_blk * (n_blk + 1) // 2 + n_blk <= 256
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
-        names = {"cholesky_solve": "cholesky_solve = %d x k_chol_step (panel k fused with the trailing update of "
-                                   "panel k-1) + k_backsolve_chain" % ((n_red + 63) // 64),
-                 "schur_syrk": "k_syrk_streamk", "eval_jacobian": "k_eval_both", "eval_cost": "k_cost"}
+        names = {"cholesky_solve": ("k_chol_dataflow (one launch: %d workgroups, %d block columns) + k_backsolve_chain"
+                                    % (n_blk * (n_blk + 1) // 2 + n_blk, n_blk)) if dataflow else
+                                   ("cholesky_solve = %d x k_chol_step + k_backsolve_chain" % n_blk),
+                 "schur_syrk": "k_syrk_streamk", "eval_jacobian": "k_eval_both + k_reduce_pose", "eval_cost": "k_cost"}
         line["roofline"] = {"kernel": names.get(dom, dom), "bound": d["bound"], "achieved": d["achieved"],
                             "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": traffic.get(dom),
+                            "traffic_source": ("profiles/%s (committed rocprofv3 --pmc passes of this command; not "
+                                               "collected in this run)" % tname) if traffic.get(dom) else None,
                             "avg_launch_ms": d["ms"]}
         if dom == "cholesky_solve":
-            # the group is a chain of launches; rocprofv3's per-kernel averages (profiles/) are per launch
-            nb = (n_red + 63) // 64
-            line["roofline"]["launches"] = {"k_chol_step": nb, "k_backsolve_chain": 1}
-            line["roofline"]["note"] = ("avg_launch_ms, achieved and traffic are for one whole factorisation + solve "
-                                        "(the %d launches above, back to back); bound by the %d dependent pivots, "
-                                        "not by the matrix cores (DESIGN.md section 4)" % (nb + 1, n_red))
+            line["roofline"]["launches"] = ({"k_chol_dataflow": 1, "k_backsolve_chain": 1} if dataflow
+                                            else {"k_chol_step": n_blk, "k_backsolve_chain": 1})
+            line["roofline"]["note"] = ("avg_launch_ms, achieved and traffic are for one whole factorisation + solve (the "
+                                        "launches above, back to back); algorithmic flops n^3/3 + 2 n^2; bound by the %d "
+                                        "dependent pivots (a chain of 8-column rounds at ~1 us each), not by the matrix "
+                                        "cores (DESIGN.md section 4)" % n_red)
         line["kernels"] = {k: {"ms": v["ms"], "bound": v["bound"], "achieved": v["achieved"],
                                "unit": v["unit"], "frac": v["frac"], "traffic": traffic.get(k)}
                            for k, v in kern.items()}
         line["kernels"]["form_z"] = {"ms": kt["form_z_ms"]}
         line["kernels"]["backsub"] = {"ms": kt["backsub_ms"]}
         line["kernels"]["lm_iteration_enqueued"] = {"ms": kt["lm_iteration_ms"]}
+        # where the device time of the timed solves went, measured on the device (vmm_ba_summary.time_*_s of the last one)
+        line["phase_report_last_solve_s"] = {k: last[k] for k in ("time_eval_s", "time_eliminate_s", "time_factor_solve_s",
+                                                                    "time_step_s", "time_control_s", "time_solve_s")}
         if not a.no_cpu_baseline:
             from oracle import oracle as O
             threads = min(os.cpu_count() or 1, 64)

@@ -26,4 +26,6 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 json.dump(out, open("gpurun_out/pmc/pmc_summary.json", "w"), indent=1)
 PY
 find gpurun_out -name '*.csv' -size +6M -delete
+# per-kernel summary of the rocprofv3 run, MFMA utilisation, traffic per launch
+python tools/pmc_to_traffic.py gpurun_out/pmc/pmc_summary.json gpurun_out/final/pmc_traffic.json > /dev/null
 ls gpurun_out/final

@@ -11,7 +11,7 @@ import json
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc/pmc_summary.json"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_traffic.json"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_traffic.json"
 d = json.load(open(src))
 
 
@@ -32,16 +32,27 @@ def traffic(names):
 
 groups = {
     "eval_jacobian": ["k_eval_both"],
-    "eval_cost": ["k_cost<true>"],
+    "eval_cost": ["k_cost<true, false>", "k_cost<true>"],
     "schur_syrk": ["k_syrk_streamk"],
     "syrk_reduce": ["k_reduce_partials<true>"],
     "form_z": ["k_form_z"],
     "chol_step": ["k_chol_step"],
+    "chol_dataflow": ["k_chol_dataflow"],
     "backsolve_chain": ["k_backsolve_chain"],
     "backsub": ["k_backsub"],
+    "reduce_pose": ["k_reduce_pose"],
 }
+bpl = {g: traffic(n) for g, n in groups.items()}
+# Calibration of the x2 read correction in THIS code's access patterns (the guide states it for 16-B-per-lane streams
+# and calls other widths uncalibrated): k_cost reads 8 B per lane, coalesced, and nothing else of size -- 72 B per tag
+# observation = 7.2 MB at 500 x 200 -- and writes a few KB.  corrected / algorithmic should be ~1 (L2 line granularity
+# and the 39 KB of poses on top); ~0.5 would mean the correction does not apply to 8-B-per-lane loads.
+n_obs = 100000
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 14 --warmup 7`, "
                  "500x200; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch (gfx950 correction)",
-       "bytes_per_launch": {g: traffic(n) for g, n in groups.items()}}
+       "calibration": {"kernel": "k_cost (8-B-per-lane coalesced SoA reads)", "algorithmic_bytes": 72.0 * n_obs,
+                       "corrected_bytes": bpl["eval_cost"],
+                       "ratio": bpl["eval_cost"] / (72.0 * n_obs) if bpl["eval_cost"] else None},
+       "bytes_per_launch": bpl}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
