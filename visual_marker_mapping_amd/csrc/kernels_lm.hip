@@ -378,11 +378,14 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
     }
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     const double* zr = Z + (int64_t)(6 * e) * ldz;
-    for (int c = lane; c < n_red; c += 64) {
-        const double yv = yf[c];
+    // 16-byte loads: n_red = 6 n_f is even and every row of Z starts 16-byte aligned (ldz is even)
+    for (int c = 2 * lane; c < n_red; c += 128) {
+        const double2 yv = *reinterpret_cast<const double2*>(yf + c);
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            acc[i] += zr[(int64_t)i * ldz + c] * yv;
+        for (int i = 0; i < 6; ++i) {
+            const double2 zv = *reinterpret_cast<const double2*>(zr + (int64_t)i * ldz + c);
+            acc[i] += zv.x * yv.x + zv.y * yv.y;
+        }
     }
     double v[6];
     double cr = 0.0;
