@@ -26,11 +26,14 @@ for tag in ("c2", "c4"):
                   "mfma_f64_instructions": c.get("SQ_INSTS_VALU_MFMA_F64", 0),
                   "busy_cu_cycles": c.get("SQ_BUSY_CU_CYCLES", 0),
                   # rocprofv3's MfmaUtil expression with SIMD_NUM = 1024 (256 CUs x 4)
-                  "mfma_util_percent": 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0) if gui else None}
+                  # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs: the kernel's active time is gui / 8
+                  "mfma_util_percent": 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * 1024.0) if gui else None,
+                  "cycles_per_mfma": c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_INSTS_VALU_MFMA_F64"] if c.get("SQ_INSTS_VALU_MFMA_F64") else None}
     out[tag] = res
 json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F64 SQ_BUSY_CU_CYCLES "
                      "on bench.py (c2: 500x200 f64, c4: 2000x1000 f32 accumulation); mfma_util_percent = "
-                     "sum(MFMA_BUSY) / (sum(GUI_ACTIVE) * 1024 SIMDs) per kernel, the MfmaUtil expression of rocprofv3 -L",
+                     "sum(MFMA_BUSY) / (sum(GUI_ACTIVE) / 8 * 1024 SIMDs) per kernel, the MfmaUtil expression of rocprofv3 -L with "
+                     "GRBM_GUI_ACTIVE (reported summed over the 8 XCDs) divided by 8",
            "kernels": out}, open("gpurun_out/mfma/mfma_util.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY
