@@ -237,19 +237,31 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
         }
         bi.swap(bi2);
         bj.swap(bj2);
-        p.n_wg = p.n_tiles * n_xcd;
-        wg_u0.resize((size_t)p.n_wg);
-        wg_u1.resize((size_t)p.n_wg);
-        wg_seg0.resize((size_t)p.n_wg);
+        // K slices per tile: as many as fit the workgroup slots (two per CU), so that every SIMD carries about the
+        // same number of MFMAs (8 slices on 440 of 512 slots left 184 CUs with two workgroups and 72 with one)
+        int n_sl = (int)std::min<int64_t>(slots / p.n_tiles, p.n_kt);
+        if (const char* v = getenv("VMM_BA_SYRK_SLICES"))
+            n_sl = std::max(1, std::min(atoi(v), p.n_kt));
+        const int n_items = p.n_tiles * n_sl;
+        const int per_x = (n_items + n_xcd - 1) / n_xcd;
+        p.n_wg = per_x * n_xcd;
+        wg_u0.assign((size_t)p.n_wg, 0);
+        wg_u1.assign((size_t)p.n_wg, 0);
+        wg_seg0.assign((size_t)p.n_wg, 0);
         for (int b = 0; b < p.n_wg; ++b) {
-            const int x = b % n_xcd, t = b / n_xcd;
-            wg_u0[b] = (int64_t)t * p.n_kt + (int64_t)p.n_kt * x / n_xcd;
-            wg_u1[b] = (int64_t)t * p.n_kt + (int64_t)p.n_kt * (x + 1) / n_xcd;
-            wg_seg0[b] = n_xcd * t + x;
+            // items in slice-major order; XCD x (blockIdx % 8) takes the x-th run of per_x items: one or two slices of K
+            const int x = b % n_xcd, j = b / n_xcd;
+            const int it = x * per_x + j;
+            if (j >= per_x || it >= n_items)
+                continue;
+            const int sl = it / p.n_tiles, t = it % p.n_tiles;
+            wg_u0[b] = (int64_t)t * p.n_kt + (int64_t)p.n_kt * sl / n_sl;
+            wg_u1[b] = (int64_t)t * p.n_kt + (int64_t)p.n_kt * (sl + 1) / n_sl;
+            wg_seg0[b] = n_sl * t + sl;
         }
         for (int t = 0; t <= p.n_tiles; ++t)
-            tile_seg0[t] = n_xcd * t;
-        seg = n_xcd * p.n_tiles;
+            tile_seg0[t] = n_sl * t;
+        seg = n_sl * p.n_tiles;
     } else {
     const int64_t full_rounds = (xcd_rounds && slots % n_xcd == 0) ? p.n_tiles / slots : 0;
     const int64_t tiles_a = full_rounds * slots;                      // one tile per workgroup
