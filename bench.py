@@ -58,7 +58,10 @@ def run_steps(ba, eng, s, opts_kw, n_steps):
         if out["num_lm_iterations"] <= 0:
             raise RuntimeError("solve made no progress: %r" % (out,))
         done += out["num_lm_iterations"]
-        evals += out["num_cost_evals"] + out["num_jacobian_evals"]
+        # passes over the observations actually executed: one combined residual + Jacobian evaluation at the
+        # candidate per LM iteration (it serves as Ceres' cost evaluation and, when accepted, as its Jacobian
+        # evaluation) plus the one of iteration zero
+        evals += out["num_cost_evals"] + 1
         solves += 1
         last = out
     return done, evals, solves, last

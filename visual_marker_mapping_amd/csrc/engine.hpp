@@ -53,13 +53,15 @@ struct LmCtl {
     // minimizer
     double x_cost, cand_cost, model_cost_change, x_norm, initial_cost;
     int32_t iteration;         // index of the iteration record being built
-    int32_t need_jacobian;     // evaluate residuals+Jacobian at x before the next step
+    int32_t need_jacobian;     // the evaluation at the candidate was accepted: its blocks become the blocks at x
     int32_t first_eval;        // the pending evaluation is iteration zero
     int32_t done, termination;
     int32_t lin_fail;          // a Cholesky pivot was not positive in this iteration
     int32_t records;           // trace rows pushed (== Ceres summary.iterations.size())
     int32_t num_successful, num_unsuccessful, num_lm_iterations, num_jac_evals, num_cost_evals;
-    int32_t trace_capacity, pad0;
+    int32_t trace_capacity;
+    int32_t w_which;           // which copy of W and of the small blocks (H, g) belongs to x; the evaluation at the
+                               // candidate writes the other one and an accepted step flips this
     vmm_ba_iteration cur;      // record under construction
     // phase report (vmm_ba_summary.time_*_s): s_memrealtime (100 MHz) stamps written by thread 0 of the first
     // kernel of each group -- 0 evaluation, 1 k_iter_begin, 2 k_elim_factor, 3 Cholesky, 4 k_backsub, 5 k_decide --
@@ -68,6 +70,9 @@ struct LmCtl {
     unsigned long long stamp[6];
     unsigned long long phase_ticks[5];
 };
+
+// Offset (doubles) of the copy of the small blocks that belongs to x.
+__device__ __forceinline__ int64_t small_sel(const LmCtl* ctl, const int64_t alt_off) { return ctl->w_which ? alt_off : 0; }
 
 // Start-of-group stamp by one thread of the launch (costs one s_memrealtime + one 8-byte store).
 __device__ __forceinline__ void phase_stamp(const LmCtl* ctl, int slot)
@@ -124,8 +129,14 @@ struct Engine {
     // where the evaluation kernels write (== the pointers above on one GPU, a staging copy that is
     // all-reduced first when world > 1)
     double* small_stage = nullptr;
+    // one GPU: the staging copy IS the second copy of the small blocks (offset from `small` in doubles; kernels add it
+    // when LmCtl::w_which is set); world > 1: 0 -- the all-reduced staging copy is copied into `small` on acceptance
+    int64_t small_alt_off = 0;
     double *ev_H_cam = nullptr, *ev_H_tag = nullptr, *ev_g_cam = nullptr, *ev_g_tag = nullptr, *ev_cost = nullptr;
     double* W = nullptr;            // [36][ordE.n_pad]: J_e^T J_f per observation, E order (f64 precision)
+    double* W2 = nullptr;           // second buffer: every LM iteration evaluates at the candidate, LmCtl::w_which says
+                                    // which one belongs to x
+    float* Wf2 = nullptr;
     uint8_t* obs_mask = nullptr;    // [n_obs] caller order, 1 = observation active (vmm_ba_set_observation_mask)
     float* Wf = nullptr;            // the same in f32 (VMM_BA_PRECISION_F32_ACCUM); exactly one of the two exists
     bool f32_accum = false;
@@ -221,7 +232,6 @@ void launch_cov_rhs(Engine& e, double* B, int ldb, bool identity_rhs);
 void launch_cov_trsm(Engine& e, double* B, int ldb, int n_chunks, bool identity_rhs);
 void launch_cov_gram(Engine& e, const double* X, int ldb, double* cov_dev);
 // kernels_lm.hip
-void launch_zero_unless_eval(Engine& e, double* buf, size_t n);
 void launch_iter_begin(Engine& e, const double* src);
 void launch_backsub(Engine& e);
 void launch_candidate(Engine& e);

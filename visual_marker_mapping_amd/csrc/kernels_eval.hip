@@ -32,6 +32,7 @@ struct EvalArgs {
     double huber_a;
     double* part;              // [n_tasks][kPart]
     void* W;                   // [36][n_pad] of AT (double or float) or null
+    void* W_alt;               // LM loop: the evaluation at the candidate writes the buffer LmCtl::w_which does NOT name
     const int32_t* caller;     // position of each sorted observation in the caller's order
     const uint8_t* mask;       // [n_obs] caller order: 0 = observation switched off (vmm_ba_set_observation_mask)
     const LmCtl* ctl;          // null: always run
@@ -56,6 +57,8 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
     const bool valid = i < t.end;
     const int64_t is = valid ? i : t.begin;
     const int o = a.other[is];
+    // LM loop: W of the candidate goes to the buffer that does not hold W at x
+    AT* __restrict__ const Wout = static_cast<AT*>((WRITE_W && a.W_alt && a.ctl && a.ctl->w_which == 0) ? a.W_alt : a.W);
 
     const int tag_idx = OWN_IS_CAM ? o : t.pose;
     const int cam_idx = OWN_IS_CAM ? t.pose : o;
@@ -162,7 +165,7 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
     if (WRITE_W && valid) {
 #pragma unroll
         for (int k = 0; k < 36; ++k)
-            static_cast<AT*>(a.W)[(int64_t)k * a.n_pad + i] = Wacc[k];
+            Wout[(int64_t)k * a.n_pad + i] = Wacc[k];
     }
     // wave reduction of the 28 family sums (21 H + 6 g + cost) in one shared butterfly
     double red[32];
@@ -224,13 +227,17 @@ struct ReduceArgs {
     double* pose_cost;   // or null
 };
 
-__global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, const ReduceArgs rE, const ReduceArgs rF)
+// alt_off != 0 (LM loop on one GPU): the blocks go to the copy of the small buffer that does NOT belong to x.
+__global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, const ReduceArgs rE, const ReduceArgs rF,
+                              const int64_t alt_off)
 {
+    int64_t off = 0;
     if (ctl) {
         if (ctl->done)
             return;
         if (guard_need_jacobian && !ctl->need_jacobian)
             return;
+        off = ctl->w_which ? 0 : alt_off;
     }
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const bool first = tid < 32 * rE.n_pose;
@@ -240,8 +247,8 @@ __global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, const R
     const int n_pose = r.n_pose;
     const int32_t* __restrict__ pose_task = r.pose_task;
     const double* __restrict__ part = r.part;
-    double* __restrict__ Hout = r.Hout;
-    double* __restrict__ gout = r.gout;
+    double* __restrict__ Hout = r.Hout + off;
+    double* __restrict__ gout = r.gout + off;
     double* __restrict__ pose_cost = r.pose_cost;
     const int p = tid >> 5, k = tid & 31;
     if (p >= n_pose || k >= 28)
@@ -470,7 +477,8 @@ __global__ void k_project(Intrinsics K, int64_t n, const double* __restrict__ pc
 
 static inline int blocks_for_tasks(int n_tasks) { return (n_tasks + 3) / 4; }
 
-static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, void* W, bool guard)
+// lm: the evaluation of the LM loop -- at the candidate poses, W into the buffer LmCtl::w_which does not name
+static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, void* W, bool guard, bool lm = false)
 {
     EvalArgs a;
     a.K = e.K;
@@ -479,8 +487,10 @@ static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, 
     a.other = ord.other;
     a.px = ord.px;
     a.n_pad = ord.n_pad;
-    a.own_pose = own_is_cam ? e.cam_qt : e.tag_qt;
-    a.other_pose = own_is_cam ? e.tag_qt : e.cam_qt;
+    const double* cam = lm ? e.cam_cand : e.cam_qt;
+    const double* tag = lm ? e.tag_cand : e.tag_qt;
+    a.own_pose = own_is_cam ? cam : tag;
+    a.other_pose = own_is_cam ? tag : cam;
     a.tag_wh = e.tag_wh;
     a.fixed_tag = e.fixed_tag;
     a.fixed_shift = e.points ? 1 : 0;
@@ -488,6 +498,7 @@ static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, 
     a.huber_a = 1.0;
     a.part = ord.part;
     a.W = W;
+    a.W_alt = (lm && W) ? (e.f32_accum ? (void*)e.Wf2 : (void*)e.W2) : nullptr;
     a.caller = ord.caller;
     a.mask = e.obs_mask;
     a.ctl = e.ctl;
@@ -545,11 +556,16 @@ void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, do
 }
 
 // Both family passes, the per-pose sums and the total cost of this rank's observations.
+// use_ctl: the evaluation of an LM iteration -- at the CANDIDATE poses, blocks into the staging copy of the small
+// buffer (they replace the working copy when the step is accepted), W into the buffer that does not hold W at x.
+// Otherwise (covariance, vmm_ba_eval_blocks, kernel timing): at the current poses, into the working copies.
 void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bool use_ctl)
 {
+    (void)guard;
     const bool e_is_cam = e.elim_cams;
-    EvalArgs aE = make_eval_args(e, e.ordE, e_is_cam, e.f32_accum ? (void*)e.Wf : (void*)e.W, guard);
-    EvalArgs aF = make_eval_args(e, e.ordF, !e_is_cam, nullptr, guard);
+    const bool lm = use_ctl;
+    EvalArgs aE = make_eval_args(e, e.ordE, e_is_cam, e.f32_accum ? (void*)e.Wf : (void*)e.W, false, lm);
+    EvalArgs aF = make_eval_args(e, e.ordF, !e_is_cam, nullptr, false, lm);
     aE.robustify = aF.robustify = robustify;
     aE.huber_a = aF.huber_a = huber_a;
     if (!use_ctl)
@@ -572,24 +588,31 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
             hipLaunchKernelGGL((k_eval_both<false>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
     }
     const LmCtl* ctl = use_ctl ? e.ctl : nullptr;
-    const int gguard = guard ? 1 : 0;
+    const int gguard = 0;
+    // LM loop, world > 1: the staging copy (all-reduced next); one GPU: the copy w_which does not name
+    const bool stage = lm && e.multi;
+    double* const oH_cam = stage ? e.ev_H_cam : e.H_cam;
+    double* const oH_tag = stage ? e.ev_H_tag : e.H_tag;
+    double* const og_cam = stage ? e.ev_g_cam : e.g_cam;
+    double* const og_tag = stage ? e.ev_g_tag : e.g_tag;
     ReduceArgs rE, rF;
     rE.n_pose = e.n_e;
     rE.pose_task = e.ordE.pose_task;
     rE.part = e.ordE.part;
-    rE.Hout = e_is_cam ? e.ev_H_cam : e.ev_H_tag;
-    rE.gout = e_is_cam ? e.ev_g_cam : e.ev_g_tag;
+    rE.Hout = e_is_cam ? oH_cam : oH_tag;
+    rE.gout = e_is_cam ? og_cam : og_tag;
     rE.pose_cost = e.part_cost;   // per-pose cost of the eliminated family
     rF.n_pose = e.n_f;
     rF.pose_task = e.ordF.pose_task;
     rF.part = e.ordF.part;
-    rF.Hout = e_is_cam ? e.ev_H_tag : e.ev_H_cam;
-    rF.gout = e_is_cam ? e.ev_g_tag : e.ev_g_cam;
+    rF.Hout = e_is_cam ? oH_tag : oH_cam;
+    rF.gout = e_is_cam ? og_tag : og_cam;
     rF.pose_cost = nullptr;
     hipLaunchKernelGGL(k_reduce_pose, dim3(((e.n_e + e.n_f) * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
-                       rE, rF);
-    if (e.multi || !use_ctl)   // single-GPU solves sum the pose costs in k_iter_begin
-        hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1, e.ev_cost);
+                       rE, rF, (lm && !e.multi) ? e.small_alt_off : (int64_t)0);
+    if (e.multi || !use_ctl)   // single-GPU solves sum the pose costs in k_decide / k_iter_begin
+        hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1,
+                           lm ? e.ev_cost : e.cost_slot);
 }
 
 void launch_sum(Engine& e, bool guard, const double* in, int n, double* out)

@@ -120,7 +120,8 @@ __device__ __forceinline__ double* pose_ptr(const PoseViews& v, int p, bool cand
 //  (c) first half of LevenbergMarquardtStrategy::ComputeStep: the LM diagonal D^2.
 __global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, const double* __restrict__ src,
                                                     double* __restrict__ dst, size_t small_count,
-                                                    const double* __restrict__ H, const double* __restrict__ g,
+                                                    const double* __restrict__ H0, const double* __restrict__ g0,
+                                                    const int64_t alt_off,
                                                     const double* __restrict__ cost_slot,
                                                     const double* __restrict__ pose_cost, int n_pose_cost,
                                                     double* __restrict__ scale, int32_t* __restrict__ active,
@@ -136,6 +137,9 @@ __global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, c
     const int tid = threadIdx.x;
     const int n_pose = pv.n_cams + pv.n_tags;
     const int n_tan = 6 * n_pose;
+    // the copy of the small blocks that belongs to x (k_decide, just before, flipped w_which if it accepted)
+    const double* __restrict__ H = H0 + small_sel(ctl, alt_off);
+    const double* __restrict__ g = g0 + small_sel(ctl, alt_off);
     if (tid == 0)
         s_evaluated = 0;
     __syncthreads();
@@ -188,7 +192,6 @@ __global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, c
         LmCtl c = *ctl;
         c.stamp[1] = t_begin;
         if (s_evaluated) {
-            c.phase_ticks[0] += t_begin > c.stamp[0] ? t_begin - c.stamp[0] : 0ull;
             const double cst = s_cst;
             const bool first = c.first_eval != 0;
             c.x_cost = cst;
@@ -339,14 +342,17 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
                                                  const double* __restrict__ ze, const double* __restrict__ scale,
                                                  double* __restrict__ step_comm, double* __restrict__ part_cross,
                                                  PoseViews pv, int f_off_pose, int n_f, int nb_e,
-                                                 double* __restrict__ delta, const double* __restrict__ H,
-                                                 const double* __restrict__ g, const int32_t* __restrict__ active,
+                                                 double* __restrict__ delta, const double* __restrict__ H0,
+                                                 const double* __restrict__ g0, const int64_t alt_off,
+                                                 const int32_t* __restrict__ active,
                                                  double* __restrict__ pose_part)
 {
     if (ctl->done)
         return;
     phase_stamp(ctl, 4);
     const bool lin_fail = ctl->lin_fail != 0;
+    const double* __restrict__ H = H0 + small_sel(ctl, alt_off);
+    const double* __restrict__ g = g0 + small_sel(ctl, alt_off);
     if (FUSE && (int)blockIdx.x >= nb_e) {
         const int f = ((int)blockIdx.x - nb_e) * blockDim.x + threadIdx.x;
         if (f >= n_f)
@@ -464,6 +470,16 @@ __global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const 
     __shared__ double sh[256];
     __shared__ int s_accept;
     const int tid = threadIdx.x;
+    if (ctl->first_eval) {
+        // iteration zero: the evaluation that just ran was at x itself (the candidate buffers start as a copy of
+        // the state); k_iter_begin takes its blocks over, W at x is the buffer the evaluation wrote
+        if (tid == 0) {
+            ctl->w_which ^= 1;
+            ctl->phase_ticks[0] += t_begin > ctl->stamp[0] ? t_begin - ctl->stamp[0] : 0ull;
+            ctl->stamp[5] = t_begin;
+        }
+        return;
+    }
     const int n_pose = pv.n_cams + pv.n_tags;
     double gd = 0.0, quad = 0.0, sn = 0.0, xn = 0.0, bad = 0.0, cross = 0.0, ccost = 0.0;
     for (int p = tid; p < n_pose; p += 256) {
@@ -546,7 +562,8 @@ __global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const 
                     c.radius = r > c.max_radius ? c.max_radius : r;
                     c.decrease_factor = 2.0;
                     c.reuse_diagonal = 0;
-                    c.need_jacobian = 1;
+                    c.need_jacobian = 1;     // the blocks evaluated at the candidate become the blocks at x
+                    c.w_which ^= 1;
                     c.x_norm = sqrt(xn);
                     c.cur.step_is_successful = 1;
                 } else {
@@ -559,12 +576,17 @@ __global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const 
             }
         }
         {
-            // phase report: the groups of this iteration (stamps of a skipped group are older than its predecessor's)
+            // phase report.  Order of the groups: evaluation at the candidate (stamp 0) -> k_decide (5) ->
+            // k_iter_begin (1) -> k_form_z (2) -> factorisation (3) -> k_backsub (4) -> next evaluation (0)
             auto span = [](unsigned long long a, unsigned long long b) { return b > a ? b - a : 0ull; };
+            c.phase_ticks[0] += span(c.stamp[0], t_begin);
+            c.phase_ticks[1] += span(c.stamp[5], c.stamp[2]);
             c.phase_ticks[2] += span(c.stamp[2], c.stamp[3]);
             c.phase_ticks[3] += span(c.stamp[3], c.stamp[4]);
-            c.phase_ticks[4] += span(c.stamp[4], t_begin);
-            c.phase_ticks[1] += span(c.stamp[1], c.stamp[2]) + span(t_begin, __builtin_amdgcn_s_memrealtime());
+            c.phase_ticks[4] += span(c.stamp[4], c.stamp[0]);
+            c.stamp[5] = t_begin;
+            if (c.done)
+                c.phase_ticks[1] += span(t_begin, __builtin_amdgcn_s_memrealtime());
         }
         *ctl = c;
         s_accept = accept;
@@ -576,17 +598,6 @@ __global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const 
         for (int i = tid; i < 7 * pv.n_tags; i += 256)
             pv.tag_qt[i] = pv.tag_cand[i];
     }
-}
-
-// Zeroes a staging buffer when this iteration did not evaluate (multi-GPU only), so the
-// unconditional all-reduce that follows is a no-op for the consumer.
-__global__ void k_zero_unless_eval(const LmCtl* ctl, double* buf, size_t n)
-{
-    if (ctl->done || ctl->need_jacobian)
-        return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        buf[i] = 0.0;
 }
 
 // ---- launchers -----------------------------------------------------------------------------------
@@ -604,16 +615,13 @@ static PoseViews views(Engine& e)
     return pv;
 }
 
-void launch_zero_unless_eval(Engine& e, double* buf, size_t n)
-{
-    hipLaunchKernelGGL(k_zero_unless_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e.stream, e.ctl, buf, n);
-}
-
 void launch_iter_begin(Engine& e, const double* src)
 {
     const bool single = !e.multi;
-    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1024), 0, e.stream, e.ctl, views(e), src, e.small, e.small_count,
-                       e.H_cam, e.g_cam, e.cost_slot, single ? e.part_cost : (const double*)nullptr, e.n_e, e.scale,
+    // one GPU: nothing to copy (src == dst), the accepted evaluation's blocks are selected through w_which
+    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1024), 0, e.stream, e.ctl, views(e), single ? e.small : src, e.small,
+                       e.small_count, e.H_cam, e.g_cam, e.small_alt_off, e.cost_slot,
+                       single ? e.part_cost : (const double*)nullptr, e.n_e, e.scale,
                        e.active, e.diag, e.D2, e.trace);
 }
 
@@ -626,13 +634,13 @@ void launch_backsub(Engine& e)
     if (e.multi) {
         hipLaunchKernelGGL((k_backsub<false>), dim3(nb_e), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
                            e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off,
-                           e.n_f, nb_e, e.delta, e.H_cam, e.g_cam, e.active, e.pose_part);
+                           e.n_f, nb_e, e.delta, e.H_cam, e.g_cam, e.small_alt_off, e.active, e.pose_part);
         return;
     }
     const int nb_f = (e.n_f + 255) / 256;
     hipLaunchKernelGGL((k_backsub<true>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
                        e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off, e.n_f,
-                       nb_e, e.delta, e.H_cam, e.g_cam, e.active, e.pose_part);
+                       nb_e, e.delta, e.H_cam, e.g_cam, e.small_alt_off, e.active, e.pose_part);
 }
 
 void launch_candidate(Engine& e)
@@ -649,9 +657,11 @@ void launch_candidate(Engine& e)
 void launch_decide(Engine& e)
 {
     const bool single = !e.multi;
+    // candidate cost: one GPU -- the per-pose costs of the evaluation at the candidate, summed here in pose order;
+    // world > 1 -- the cost slot of the all-reduced staging buffer
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), e.pose_part,
                        e.step_comm + 6 * (size_t)e.n_e, single ? e.part_cross : (const double*)nullptr, e.n_e,
-                       e.cost_comm, single ? e.part_k1 : (const double*)nullptr, e.ordE.n_tasks);
+                       e.ev_cost, single ? e.part_cost : (const double*)nullptr, e.n_e);
 }
 
 // Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources
@@ -665,7 +675,6 @@ int preload_lm_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<false>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_candidate)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_decide)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_zero_unless_eval)) != hipSuccess;
     return bad;
 }
 

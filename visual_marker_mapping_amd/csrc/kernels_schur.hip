@@ -55,8 +55,9 @@ template <typename WT>
 __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64_t n_pad,
                                                  const int32_t* __restrict__ own,
                                                  const int32_t* __restrict__ other,
-                                                 const WT* __restrict__ W,
-                                                 const double* __restrict__ H_E, const double* __restrict__ g_E,
+                                                 const WT* __restrict__ W0, const WT* __restrict__ W1,
+                                                 const double* __restrict__ H_E0, const double* __restrict__ g_E0,
+                                                 const int64_t alt_off,
                                                  const double* __restrict__ D2,
                                                  double* __restrict__ Le, double* __restrict__ ze,
                                                  const double* __restrict__ scale, int e_off_pose,
@@ -68,6 +69,9 @@ __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_obs)
         return;
+    const WT* __restrict__ W = ctl->w_which ? W1 : W0;   // the buffer that holds J_e^T J_f at x
+    const double* __restrict__ H_E = H_E0 + small_sel(ctl, alt_off);
+    const double* __restrict__ g_E = g_E0 + small_sel(ctl, alt_off);
     const int e = own[i], f = other[i];
     const double* se = scale + 6 * (int64_t)(e_off_pose + e);
     const double* sf = scale + 6 * (int64_t)(f_off_pose + f);
@@ -279,6 +283,7 @@ struct DiagArgs {        // kept family's damped diagonal blocks and rhs, added 
     const double* scale_F;   // scale + 6 * f_off
     const double* D2_F;      // D2 + 6 * f_off
     int n_red, n_pad;
+    int64_t alt_off;         // H_F, g_F live in the copy of the small blocks LmCtl::w_which names
 };
 
 // S(tile) = -(sum of the tile's partials, in segment order) [+ damped diagonal blocks / rhs / padding].
@@ -299,6 +304,10 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const LmCtl* ctl, SyrkP
         return;
     const int s0 = pl.tile_seg0[t], s1 = pl.tile_seg0[t + 1];
     const int tr = 16 * rs + (threadIdx.x >> 5), tc = (threadIdx.x & 31) * 2;   // rows tr, tr + 8
+    if (ADD_DIAG && ctl) {
+        da.H_F += small_sel(ctl, da.alt_off);
+        da.g_F += small_sel(ctl, da.alt_off);
+    }
     double2 acc[2] = { make_double2(0.0, 0.0), make_double2(0.0, 0.0) };
     const double* p0 = pl.partials + (size_t)(64 * qi + tr) * kSyrkT + 64 * qj + tc;
 #pragma unroll 4
@@ -396,11 +405,11 @@ void launch_elim(Engine& e)
         const dim3 grid((unsigned)((e.ordE.n + 255) / 256));
         if (e.f32_accum)
             hipLaunchKernelGGL((k_form_z<float>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,
-                               e.ordE.other, (const float*)e.Wf, H_E, g_E, (const double*)e.D2, e.Le, e.ze, e.scale, e_off,
+                               e.ordE.other, (const float*)e.Wf, (const float*)e.Wf2, H_E, g_E, e.small_alt_off, (const double*)e.D2, e.Le, e.ze, e.scale, e_off,
                                f_off, e.Z, e.ldz, e.n_pad);
         else
             hipLaunchKernelGGL((k_form_z<double>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,
-                               e.ordE.other, (const double*)e.W, H_E, g_E, (const double*)e.D2, e.Le, e.ze, e.scale, e_off,
+                               e.ordE.other, (const double*)e.W, (const double*)e.W2, H_E, g_E, e.small_alt_off, (const double*)e.D2, e.Le, e.ze, e.scale, e_off,
                                f_off, e.Z, e.ldz, e.n_pad);
     }
 }
@@ -438,6 +447,7 @@ void launch_syrk_reduced(Engine& e)
     da.D2_F = e.D2 + 6 * (size_t)f_off;
     da.n_red = e.n_red;
     da.n_pad = e.n_pad;
+    da.alt_off = e.small_alt_off;
     hipLaunchKernelGGL((k_reduce_partials<true>), dim3(16 * e.syrk.n_tiles), dim3(256), 0, e.stream, e.ctl,
                        plan_dev(e.syrk), e.ldz, e.n_pad + 1, e.S, da);
 }

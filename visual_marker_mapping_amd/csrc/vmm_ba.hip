@@ -478,18 +478,24 @@ static void destroy_engine(Engine* e)
     delete e;
 }
 
-// One LM iteration as a fixed sequence of guarded kernels (+ all-reduces when world > 1).
-// One LM iteration = five groups of guarded kernels separated (world > 1) by the four sum-all-reduces.
+// One LM iteration = four groups of kernels separated (world > 1) by the three sum-all-reduces.
+//
+// Every iteration evaluates residuals AND Jacobians at the CANDIDATE x + delta of the previous iteration (iteration
+// zero: the candidate buffers start as a copy of x).  Its cost is the cost Ceres evaluates at the candidate; when the
+// step is accepted its blocks simply become the blocks at the new x (staging copy -> working copy, the other W
+// buffer), so an accepted step -- the common case -- costs one evaluation instead of a cost pass plus a Jacobian
+// pass, and the accept/reject decision sits directly in front of the next iteration's set-up.  A rejected step
+// wastes the Jacobian part of its evaluation (21 us of a 0.5 ms iteration at 500 x 200).
+constexpr int kNumSeg = 4;
 static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg)
 {
     switch (seg) {
     case 0:
-        launch_eval_passes(e, true, o.robustify, o.huber_a, true);
-        if (e.multi)
-            launch_zero_unless_eval(e, e.small_stage, e.small_count);
+        launch_eval_passes(e, false, o.robustify, o.huber_a, true);
         break;
     case 1:
-        launch_iter_begin(e, e.multi ? e.small_stage : e.small);
+        launch_decide(e);
+        launch_iter_begin(e, e.small_stage);
         launch_elim(e);
         launch_syrk_reduced(e);
         launch_pack_lower(e, false);
@@ -502,15 +508,8 @@ static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg)
         if (e.multi)
             launch_sum(e, true, e.part_cross, e.n_e, e.step_comm + 6 * (size_t)e.n_e);
         break;
-    case 3:
-        launch_candidate(e);
-        if (e.multi)
-            launch_cost(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a, e.cost_comm);
-        else
-            launch_cost_kernel(e, e.cam_cand, e.tag_cand, true, o.robustify, o.huber_a);   // summed by k_decide
-        break;
     default:
-        launch_decide(e);
+        launch_candidate(e);   // world > 1 only; one GPU forms the candidates in k_backsub
         break;
     }
 }
@@ -519,20 +518,21 @@ static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg)
 static int allreduce_after(Engine& e, int seg)
 {
     switch (seg) {
-    case 0: return do_allreduce(e, e.small_stage, e.small_count);
+    case 0: return do_allreduce(e, e.small_stage, e.small_count);   // blocks, gradient and cost at the candidate
     case 1: return do_allreduce(e, e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2);
     case 2: return do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1);
-    case 3: return do_allreduce(e, e.cost_comm, 1);
     default: return VMM_BA_OK;
     }
 }
 
 static int enqueue_iteration(Engine& e, const vmm_ba_options& o)
 {
-    static const char* const names[5] = { "vmm_ba evaluation", "vmm_ba eliminate + rank-k", "vmm_ba factor + solve",
-                                          "vmm_ba candidate + cost", "vmm_ba decide" };
+    static const char* const names[kNumSeg] = { "vmm_ba evaluation at the candidate", "vmm_ba decide + eliminate + rank-k",
+                                                "vmm_ba factor + solve + step", "vmm_ba candidate" };
     int rc;
-    for (int seg = 0; seg < 5; ++seg) {
+    for (int seg = 0; seg < kNumSeg; ++seg) {
+        if (seg == kNumSeg - 1 && !e.multi)
+            break;   // one GPU: the candidates are formed by k_backsub
         Range r(names[seg]);
         enqueue_segment(e, o, seg);
         if (e.multi && (rc = allreduce_after(e, seg)))
@@ -600,14 +600,14 @@ static void drop_graphs(Engine& e)
     }
 }
 
-static const char* const kSegName[5] = { "evaluation", "control + eliminate + rank-k update", "factor + solve + back-substitution",
-                                         "candidate + cost", "decide" };
+static const char* const kSegName[kNumSeg] = { "evaluation at the candidate", "decide + control + eliminate + rank-k update",
+                                               "factor + solve + back-substitution", "candidate" };
 
 // The iteration is captured once into hipGraphs and replayed (eager enqueueing is host-bound).
 //   one GPU:                      one graph;
-//   world > 1, RCCL communicator: one graph, the four ncclAllReduce calls recorded between the kernel groups
-//                                 (VMM_BA_RCCL_GRAPH=0: five graphs with the collectives enqueued between them);
-//   world > 1, host callback:     the callbacks are host calls, so the five kernel groups between them are five graphs.
+//   world > 1, RCCL communicator: one graph, the three ncclAllReduce calls recorded between the kernel groups
+//                                 (VMM_BA_RCCL_GRAPH=0: four graphs with the collectives enqueued between them);
+//   world > 1, host callback:     the callbacks are host calls, so the four kernel groups around them are four graphs.
 // No kernel is launched for the first time under capture: vmm_ba_create touches every kernel (preload_*_kernels).
 // Round 1 ran the first iteration of a handle eagerly because of an intermittent "operation failed due to a previous
 // error during capture" at 2000 x 1000; VMM_BA_EAGER_FIRST=1 brings that back.
@@ -626,7 +626,7 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
         int rc;
         if (one_graph) {
             rc = capture_graph(e, &e.iter_graph, [&](const char** where) -> int {
-                for (int seg = 0; seg < 5; ++seg) {
+                for (int seg = 0; seg < kNumSeg; ++seg) {
                     enqueue_segment(e, o, seg);
                     int r;
                     if (e.multi && (r = allreduce_after(e, seg)))
@@ -644,7 +644,7 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
             if (rc)
                 return rc;
         } else {
-            for (int seg = 0; seg < 5; ++seg)
+            for (int seg = 0; seg < kNumSeg; ++seg)
                 if ((rc = capture_graph(e, &e.iter_graph_seg[seg], [&](const char** where) -> int {
                          enqueue_segment(e, o, seg);
                          if (capture_alive(e))
@@ -664,11 +664,23 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
         return VMM_BA_OK;
     }
     int rc;
-    for (int seg = 0; seg < 5; ++seg) {
+    for (int seg = 0; seg < kNumSeg; ++seg) {
         HIP_TRY(hipGraphLaunch(e.iter_graph_seg[seg], e.stream));
         if ((rc = allreduce_after(e, seg)))
             return rc;
     }
+    return VMM_BA_OK;
+}
+
+static void init_ctl(LmCtl& c, const vmm_ba_options& o, int trace_capacity);
+
+// Control block and candidate buffers at the start of an LM loop: iteration zero evaluates "the candidate" = x.
+static int begin_lm_loop(Engine& e, const vmm_ba_options& o, int trace_capacity)
+{
+    init_ctl(*e.ctl_host, o, trace_capacity);
+    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+    HIP_TRY(hipMemcpyAsync(e.cam_cand, e.cam_qt, sizeof(double) * 7 * e.n_cams, hipMemcpyDeviceToDevice, e.stream));
+    HIP_TRY(hipMemcpyAsync(e.tag_cand, e.tag_qt, sizeof(double) * 7 * e.n_tags, hipMemcpyDeviceToDevice, e.stream));
     return VMM_BA_OK;
 }
 
@@ -926,11 +938,10 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.g_cam = e.H_tag + (size_t)36 * e.n_tags;
     e.g_tag = e.g_cam + (size_t)6 * e.n_cams;
     e.cost_slot = e.g_tag + (size_t)6 * e.n_tags;
-    if (e.multi) {
-        if ((rc = dev_alloc(e, &e.small_stage, e.small_count))) return fail(rc);
-    } else {
-        e.small_stage = e.small;
-    }
+    // the LM loop evaluates at the candidate into this staging copy (all-reduced when world > 1); it replaces the
+    // working copy when the step is accepted
+    if ((rc = dev_alloc(e, &e.small_stage, e.small_count))) return fail(rc);
+    e.small_alt_off = e.multi ? 0 : (int64_t)(e.small_stage - e.small);
     e.ev_H_cam = e.small_stage;
     e.ev_H_tag = e.ev_H_cam + (size_t)36 * e.n_cams;
     e.ev_g_cam = e.ev_H_tag + (size_t)36 * e.n_tags;
@@ -949,7 +960,11 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     }
     if (e.f32_accum) {
         if ((rc = dev_alloc(e, &e.Wf, (size_t)36 * e.ordE.n_pad))) return fail(rc);
-    } else if ((rc = dev_alloc(e, &e.W, (size_t)36 * e.ordE.n_pad))) return fail(rc);
+        if ((rc = dev_alloc(e, &e.Wf2, (size_t)36 * e.ordE.n_pad))) return fail(rc);
+    } else {
+        if ((rc = dev_alloc(e, &e.W, (size_t)36 * e.ordE.n_pad))) return fail(rc);
+        if ((rc = dev_alloc(e, &e.W2, (size_t)36 * e.ordE.n_pad))) return fail(rc);
+    }
     if ((rc = dev_alloc(e, &e.scale, (size_t)6 * n_pose))) return fail(rc);
     if ((rc = dev_alloc(e, &e.diag, (size_t)6 * n_pose))) return fail(rc);
     if ((rc = dev_alloc(e, &e.D2, (size_t)6 * n_pose))) return fail(rc);
@@ -1184,8 +1199,10 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
         if ((rc = dev_alloc(e, &e.trace, (size_t)need_cap, false))) return rc;
         e.trace_capacity = need_cap;
     }
-    init_ctl(*e.ctl_host, o, user_cap);
-    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+    {
+        int rc;
+        if ((rc = begin_lm_loop(e, o, user_cap))) return rc;
+    }
 
     const int poll = std::max(1, o.poll_interval);
     const int64_t max_steps = (int64_t)o.max_num_iterations + 2;
@@ -1428,11 +1445,11 @@ int vmm_ba_eval_blocks(vmm_ba_handle h, int robustify, double huber_a, double* c
     HIP_TRY(hipSetDevice(e.device));
     launch_eval_passes(e, false, robustify, huber_a, false);
     HIP_TRY(hipGetLastError());
-    if (cost) HIP_TRY(hipMemcpyAsync(cost, e.ev_cost, sizeof(double), hipMemcpyDeviceToHost, e.stream));
-    if (V) HIP_TRY(hipMemcpyAsync(V, e.ev_H_cam, sizeof(double) * 36 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
-    if (U) HIP_TRY(hipMemcpyAsync(U, e.ev_H_tag, sizeof(double) * 36 * e.n_tags, hipMemcpyDeviceToHost, e.stream));
-    if (g_cam) HIP_TRY(hipMemcpyAsync(g_cam, e.ev_g_cam, sizeof(double) * 6 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
-    if (g_tag) HIP_TRY(hipMemcpyAsync(g_tag, e.ev_g_tag, sizeof(double) * 6 * e.n_tags, hipMemcpyDeviceToHost, e.stream));
+    if (cost) HIP_TRY(hipMemcpyAsync(cost, e.cost_slot, sizeof(double), hipMemcpyDeviceToHost, e.stream));
+    if (V) HIP_TRY(hipMemcpyAsync(V, e.H_cam, sizeof(double) * 36 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
+    if (U) HIP_TRY(hipMemcpyAsync(U, e.H_tag, sizeof(double) * 36 * e.n_tags, hipMemcpyDeviceToHost, e.stream));
+    if (g_cam) HIP_TRY(hipMemcpyAsync(g_cam, e.g_cam, sizeof(double) * 6 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
+    if (g_tag) HIP_TRY(hipMemcpyAsync(g_tag, e.g_tag, sizeof(double) * 6 * e.n_tags, hipMemcpyDeviceToHost, e.stream));
     HIP_TRY(hipStreamSynchronize(e.stream));
     if (W && e.n_obs > 0) {
         std::vector<double> w((size_t)36 * e.ordE.n_pad);
@@ -1624,8 +1641,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     ot.function_tolerance = 0.0;
     ot.parameter_tolerance = 0.0;
     ot.gradient_tolerance = 0.0;
-    init_ctl(*e.ctl_host, ot, 0);
-    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+    if ((rc = begin_lm_loop(e, ot, 0))) return rc;
     if ((rc = enqueue_iteration(e, ot))) return rc;   // populates every buffer of an iteration
     HIP_TRY(hipStreamSynchronize(e.stream));
     // the priming step was accepted and moved x; go back so that the W recomputed by the timed
@@ -1689,8 +1705,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     }
     // whole iterations from the caller's state
     if ((rc = vmm_ba_set_state(h, cam0.data(), tag0.data()))) return rc;
-    init_ctl(*e.ctl_host, ot, 0);
-    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+    if ((rc = begin_lm_loop(e, ot, 0))) return rc;
     HIP_TRY(hipEventRecord(ev0, e.stream));
     for (int r = 0; r < reps; ++r)
         if ((rc = run_iteration(e, ot))) return rc;
