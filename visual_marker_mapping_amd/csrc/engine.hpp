@@ -64,7 +64,7 @@ struct LmCtl {
                                // candidate writes the other one and an accepted step flips this
     vmm_ba_iteration cur;      // record under construction
     // phase report (vmm_ba_summary.time_*_s): s_memrealtime (100 MHz) stamps written by thread 0 of the first
-    // kernel of each group -- 0 evaluation, 1 k_iter_begin, 2 k_elim_factor, 3 Cholesky, 4 k_backsub, 5 k_decide --
+    // kernel of each group -- 0 evaluation at the candidate, 1 unused, 2 k_form_z, 3 Cholesky, 4 k_backsub, 5 k_control --
     // and their differences accumulated per solve: 0 evaluation, 1 control, 2 eliminate + rank-k update,
     // 3 factor + triangular solves, 4 step (back-substitution, candidate, cost at the candidate)
     unsigned long long stamp[6];
@@ -232,9 +232,8 @@ void launch_cov_rhs(Engine& e, double* B, int ldb, bool identity_rhs);
 void launch_cov_trsm(Engine& e, double* B, int ldb, int n_chunks, bool identity_rhs);
 void launch_cov_gram(Engine& e, const double* X, int ldb, double* cov_dev);
 // kernels_lm.hip
-void launch_iter_begin(Engine& e, const double* src);
+void launch_control(Engine& e);
 void launch_backsub(Engine& e);
 void launch_candidate(Engine& e);
-void launch_decide(Engine& e);
 
 } // namespace vmm

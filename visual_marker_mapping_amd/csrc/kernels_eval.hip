@@ -610,7 +610,7 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
     rF.pose_cost = nullptr;
     hipLaunchKernelGGL(k_reduce_pose, dim3(((e.n_e + e.n_f) * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
                        rE, rF, (lm && !e.multi) ? e.small_alt_off : (int64_t)0);
-    if (e.multi || !use_ctl)   // single-GPU solves sum the pose costs in k_decide / k_iter_begin
+    if (e.multi || !use_ctl)   // single-GPU solves sum the pose costs in k_control
         hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1,
                            lm ? e.ev_cost : e.cost_slot);
 }

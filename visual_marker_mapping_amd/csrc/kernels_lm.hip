@@ -112,45 +112,202 @@ __device__ __forceinline__ double* pose_ptr(const PoseViews& v, int p, bool cand
     return (cand ? v.tag_cand : v.tag_qt) + 7 * (int64_t)(p - v.n_cams);
 }
 
-// First kernel of an iteration's control flow, one block:
-//  (a) if an evaluation at x just ran (TrustRegionMinimizer::IterationZero /
-//      EvaluateGradientAndJacobian): total cost, Jacobi scaling (first evaluation only), gradient
-//      max-norm |Plus(x,-g) - x|_inf, completion of the pending iteration record;
+// The control kernel of an LM iteration, one block, between the evaluation at the candidate and the elimination:
+//  (0) the decision on the step whose candidate was just evaluated -- ComputeTrustRegionStep (model cost),
+//      ParameterToleranceReached, FunctionToleranceReached, IsStepSuccessful, HandleSuccessfulStep /
+//      HandleUnsuccessfulStep / HandleInvalidStep, LevenbergMarquardtStrategy::StepAccepted / StepRejected; an
+//      accepted candidate becomes x and its evaluation becomes the evaluation at x (w_which flips).  Iteration zero
+//      has no step to judge: the evaluation was at x itself;
+//  (a) if x moved (TrustRegionMinimizer::IterationZero / EvaluateGradientAndJacobian): total cost, Jacobi scaling
+//      (first evaluation only), gradient max-norm |Plus(x,-g) - x|_inf, completion of the pending iteration record;
 //  (b) FinalizeIterationAndCheckIfMinimizerCanContinue: push the record, termination tests;
 //  (c) first half of LevenbergMarquardtStrategy::ComputeStep: the LM diagonal D^2.
-__global__ __launch_bounds__(1024) void k_iter_begin(LmCtl* ctl, PoseViews pv, const double* __restrict__ src,
-                                                    double* __restrict__ dst, size_t small_count,
-                                                    const double* __restrict__ H0, const double* __restrict__ g0,
-                                                    const int64_t alt_off,
-                                                    const double* __restrict__ cost_slot,
-                                                    const double* __restrict__ pose_cost, int n_pose_cost,
-                                                    double* __restrict__ scale, int32_t* __restrict__ active,
-                                                    double* __restrict__ diag, double* __restrict__ D2,
-                                                    vmm_ba_iteration* __restrict__ trace)
+// (Two kernels until the evaluation moved to the candidate put them next to each other; one launch saves the
+// dependent-launch gap and a second read-modify-write of the control block.)
+struct DecideArgs {
+    const double* pose_part;        // [n_pose][5], k_backsub / k_candidate
+    const double* cross_slot;       // world > 1: all-reduced cross term
+    const double* cross_parts;      // one GPU: its per-pose partials, summed here in pose order
+    int n_cross;
+    const double* cand_cost_slot;   // world > 1: cost slot of the all-reduced staging copy
+    const double* cost_parts;       // one GPU: per-pose costs of the evaluation at the candidate
+    int n_cost;
+};
+
+__global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, const DecideArgs dz,
+                                                 const double* __restrict__ src, double* __restrict__ dst,
+                                                 size_t small_count, const double* __restrict__ H0,
+                                                 const double* __restrict__ g0, const int64_t alt_off,
+                                                 const double* __restrict__ cost_slot,
+                                                 const double* __restrict__ pose_cost, int n_pose_cost,
+                                                 double* __restrict__ scale, int32_t* __restrict__ active,
+                                                 double* __restrict__ diag, double* __restrict__ D2,
+                                                 vmm_ba_iteration* __restrict__ trace)
 {
     if (ctl->done)
         return;
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     __shared__ double sh[256];
-    __shared__ int s_stop, s_reuse, s_evaluated;
+    __shared__ int s_stop, s_reuse, s_evaluated, s_accept, s_need, s_first, s_which, s_done;
     __shared__ double s_radius, s_lo, s_hi, s_xn, s_gm, s_cst;
     const int tid = threadIdx.x;
     const int n_pose = pv.n_cams + pv.n_tags;
+    // ---- (0) the step decision ----
+    if (ctl->first_eval) {
+        if (tid == 0) {
+            const int which = ctl->w_which ^ 1;   // W and the small blocks at x: what the evaluation just wrote
+            ctl->w_which = which;
+            ctl->phase_ticks[0] += t_begin > ctl->stamp[0] ? t_begin - ctl->stamp[0] : 0ull;
+            ctl->stamp[5] = t_begin;
+            s_accept = 0;
+            s_need = 1;
+            s_first = 1;
+            s_which = which;
+            s_done = 0;
+        }
+    } else {
+        if (tid == 0)
+            s_first = 0;
+        double gd = 0.0, quad = 0.0, sn = 0.0, xn = 0.0, bad = 0.0, cross = 0.0, ccost = 0.0;
+        for (int p = tid; p < n_pose; p += (int)blockDim.x) {
+            const double* o = dz.pose_part + 5 * (int64_t)p;
+            gd += o[0];
+            quad += o[1];
+            sn += o[2];
+            xn += o[3];
+            bad = fmax(bad, o[4]);
+        }
+        // single GPU: the wave partials of the cross term and of the candidate cost are summed here
+        // (fixed order); with world > 1 they were summed and all-reduced before (scalar slots)
+        if (dz.cross_parts)
+            for (int i = tid; i < dz.n_cross; i += (int)blockDim.x)
+                cross += dz.cross_parts[i];
+        if (dz.cost_parts)
+            for (int i = tid; i < dz.n_cost; i += (int)blockDim.x)
+                ccost += dz.cost_parts[i];
+        double red[7] = { gd, quad, sn, xn, cross, ccost, bad };
+        block_reduce_multi<6, 1>(red, sh);
+        gd = red[0];
+        quad = red[1];
+        sn = red[2];
+        xn = red[3];
+        cross = dz.cross_parts ? red[4] : dz.cross_slot[0];
+        ccost = dz.cost_parts ? red[5] : dz.cand_cost_slot[0];
+        bad = red[6];
+        if (tid == 0) {
+            // one load and one store of the control block: field-by-field global accesses cost ~0.5 us each
+            LmCtl c = *ctl;
+            int accept = 0;
+            const bool lin_fail = c.lin_fail != 0 || bad != 0.0;
+            // model_cost_change = -(J d)^T (r + J d / 2) = -d^T g - 1/2 d^T H d   (unscaled coordinates)
+            const double mcc = lin_fail ? 0.0 : -gd - 0.5 * (quad + 2.0 * cross);
+            c.model_cost_change = mcc;
+            c.cur.model_cost_change = mcc;
+            const bool valid = !lin_fail && (mcc > 0.0);
+            c.cur.step_is_valid = valid ? 1 : 0;
+            if (!valid) {
+                // HandleInvalidStep
+                c.num_invalid++;
+                if (c.num_invalid >= c.max_invalid) {
+                    c.done = 1;
+                    c.termination = VMM_BA_FAILURE;
+                } else {
+                    c.radius = c.radius / c.decrease_factor;
+                    c.decrease_factor *= 2.0;
+                    c.reuse_diagonal = 1;
+                    c.cur.cost = c.x_cost;
+                    c.cur.step_is_successful = 0;
+                }
+            } else {
+                c.num_invalid = 0;
+                double cand = ccost;
+                c.num_cost_evals++;
+                if (!isfinite(cand))
+                    cand = DBL_MAX;
+                c.cand_cost = cand;
+                const double step_norm = sqrt(sn);
+                c.cur.step_norm = step_norm;
+                const double x_cost = c.x_cost;
+                const double cost_change = x_cost - cand;
+                if (step_norm <= c.parameter_tolerance * (c.x_norm + c.parameter_tolerance)) {
+                    c.done = 1;   // ParameterToleranceReached: return without pushing this record
+                    c.termination = VMM_BA_CONVERGENCE;
+                } else if (fabs(cost_change) <= c.function_tolerance * x_cost) {
+                    c.cur.cost_change = cost_change;
+                    c.done = 1;   // FunctionToleranceReached
+                    c.termination = VMM_BA_CONVERGENCE;
+                } else {
+                    c.cur.cost_change = cost_change;
+                    const double rd = (cand >= DBL_MAX) ? -DBL_MAX : cost_change / mcc;
+                    c.cur.relative_decrease = rd;
+                    if (rd > c.min_relative_decrease) {
+                        accept = 1;
+                        const double q = 2.0 * rd - 1.0;
+                        double den = 1.0 - q * q * q;
+                        den = den < 1.0 / 3.0 ? 1.0 / 3.0 : den;
+                        double r = c.radius / den;
+                        c.radius = r > c.max_radius ? c.max_radius : r;
+                        c.decrease_factor = 2.0;
+                        c.reuse_diagonal = 0;
+                        c.need_jacobian = 1;     // the blocks evaluated at the candidate become the blocks at x
+                        c.w_which ^= 1;
+                        c.x_norm = sqrt(xn);
+                        c.cur.step_is_successful = 1;
+                    } else {
+                        c.cur.step_is_successful = 0;
+                        c.cur.cost = cand;
+                        c.radius = c.radius / c.decrease_factor;
+                        c.decrease_factor *= 2.0;
+                        c.reuse_diagonal = 1;
+                    }
+                }
+            }
+            {
+                // phase report.  Order of the groups: evaluation at the candidate (stamp 0) -> this kernel (5) ->
+                // k_form_z (2) -> factorisation (3) -> k_backsub (4) -> next evaluation (0)
+                auto span = [](unsigned long long a, unsigned long long b) { return b > a ? b - a : 0ull; };
+                c.phase_ticks[0] += span(c.stamp[0], t_begin);
+                c.phase_ticks[1] += span(c.stamp[5], c.stamp[2]);
+                c.phase_ticks[2] += span(c.stamp[2], c.stamp[3]);
+                c.phase_ticks[3] += span(c.stamp[3], c.stamp[4]);
+                c.phase_ticks[4] += span(c.stamp[4], c.stamp[0]);
+                c.stamp[5] = t_begin;
+                if (c.done)
+                    c.phase_ticks[1] += span(t_begin, __builtin_amdgcn_s_memrealtime());
+            }
+            *ctl = c;
+            s_accept = accept;
+            s_need = c.need_jacobian;
+            s_which = c.w_which;
+            s_done = c.done;
+        }
+    }
+    __syncthreads();
+    if (s_accept) {
+        for (int i = tid; i < 7 * pv.n_cams; i += (int)blockDim.x)
+            pv.cam_qt[i] = pv.cam_cand[i];
+        for (int i = tid; i < 7 * pv.n_tags; i += (int)blockDim.x)
+            pv.tag_qt[i] = pv.tag_cand[i];
+    }
+    if (s_done)
+        return;
+    __syncthreads();   // the new x is in place before (a) reads it
+    // ---- (a), (b), (c) ----
     const int n_tan = 6 * n_pose;
-    // the copy of the small blocks that belongs to x (k_decide, just before, flipped w_which if it accepted)
-    const double* __restrict__ H = H0 + small_sel(ctl, alt_off);
-    const double* __restrict__ g = g0 + small_sel(ctl, alt_off);
+    // the copy of the small blocks that belongs to x (an accepted step has just flipped w_which)
+    const double* __restrict__ H = H0 + (s_which ? alt_off : 0);
+    const double* __restrict__ g = g0 + (s_which ? alt_off : 0);
     if (tid == 0)
         s_evaluated = 0;
     __syncthreads();
-    if (ctl->need_jacobian) {
+    if (s_need) {
         // multi-GPU: the all-reduced staging buffer becomes the working copy
         if (src != dst) {
             for (size_t i = tid; i < small_count; i += blockDim.x)
                 dst[i] = src[i];
             __syncthreads();
         }
-        const bool first = ctl->first_eval != 0;
+        const bool first = s_first != 0;
         const bool jacobi = ctl->jacobi_scaling != 0;
         double xn = 0.0, gm = 0.0, cst = 0.0;
         for (int p = tid; p < n_pose; p += (int)blockDim.x) {
@@ -454,152 +611,6 @@ __global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_p
     candidate_for_pose(pv, p, d, delta, H, g, active, pose_part);
 }
 
-// Step validation, convergence tests, acceptance and radius update:
-// ComputeTrustRegionStep (model cost), ParameterToleranceReached, FunctionToleranceReached,
-// IsStepSuccessful, HandleSuccessfulStep / HandleUnsuccessfulStep / HandleInvalidStep,
-// LevenbergMarquardtStrategy::StepAccepted / StepRejected.
-__global__ __launch_bounds__(256) void k_decide(LmCtl* ctl, PoseViews pv, const double* __restrict__ pose_part,
-                                                const double* __restrict__ cross_slot,
-                                                const double* __restrict__ cross_parts, int n_cross,
-                                                const double* __restrict__ cand_cost_slot,
-                                                const double* __restrict__ cost_parts, int n_cost)
-{
-    if (ctl->done)
-        return;
-    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-    __shared__ double sh[256];
-    __shared__ int s_accept;
-    const int tid = threadIdx.x;
-    if (ctl->first_eval) {
-        // iteration zero: the evaluation that just ran was at x itself (the candidate buffers start as a copy of
-        // the state); k_iter_begin takes its blocks over, W at x is the buffer the evaluation wrote
-        if (tid == 0) {
-            ctl->w_which ^= 1;
-            ctl->phase_ticks[0] += t_begin > ctl->stamp[0] ? t_begin - ctl->stamp[0] : 0ull;
-            ctl->stamp[5] = t_begin;
-        }
-        return;
-    }
-    const int n_pose = pv.n_cams + pv.n_tags;
-    double gd = 0.0, quad = 0.0, sn = 0.0, xn = 0.0, bad = 0.0, cross = 0.0, ccost = 0.0;
-    for (int p = tid; p < n_pose; p += 256) {
-        const double* o = pose_part + 5 * (int64_t)p;
-        gd += o[0];
-        quad += o[1];
-        sn += o[2];
-        xn += o[3];
-        bad = fmax(bad, o[4]);
-    }
-    // single GPU: the wave partials of the cross term and of the candidate cost are summed here
-    // (fixed order); with world > 1 they were summed and all-reduced before (scalar slots)
-    if (cross_parts)
-        for (int i = tid; i < n_cross; i += 256)
-            cross += cross_parts[i];
-    if (cost_parts)
-        for (int i = tid; i < n_cost; i += 256)
-            ccost += cost_parts[i];
-    double red[7] = { gd, quad, sn, xn, cross, ccost, bad };
-    block_reduce_multi<6, 1>(red, sh);
-    gd = red[0];
-    quad = red[1];
-    sn = red[2];
-    xn = red[3];
-    cross = cross_parts ? red[4] : cross_slot[0];
-    ccost = cost_parts ? red[5] : cand_cost_slot[0];
-    bad = red[6];
-    if (tid == 0) {
-        // one load and one store of the control block (see k_iter_begin)
-        LmCtl c = *ctl;
-        int accept = 0;
-        const bool lin_fail = c.lin_fail != 0 || bad != 0.0;
-        // model_cost_change = -(J d)^T (r + J d / 2) = -d^T g - 1/2 d^T H d   (unscaled coordinates)
-        const double mcc = lin_fail ? 0.0 : -gd - 0.5 * (quad + 2.0 * cross);
-        c.model_cost_change = mcc;
-        c.cur.model_cost_change = mcc;
-        const bool valid = !lin_fail && (mcc > 0.0);
-        c.cur.step_is_valid = valid ? 1 : 0;
-        if (!valid) {
-            // HandleInvalidStep
-            c.num_invalid++;
-            if (c.num_invalid >= c.max_invalid) {
-                c.done = 1;
-                c.termination = VMM_BA_FAILURE;
-            } else {
-                c.radius = c.radius / c.decrease_factor;
-                c.decrease_factor *= 2.0;
-                c.reuse_diagonal = 1;
-                c.cur.cost = c.x_cost;
-                c.cur.step_is_successful = 0;
-            }
-        } else {
-            c.num_invalid = 0;
-            double cand = ccost;
-            c.num_cost_evals++;
-            if (!isfinite(cand))
-                cand = DBL_MAX;
-            c.cand_cost = cand;
-            const double step_norm = sqrt(sn);
-            c.cur.step_norm = step_norm;
-            const double x_cost = c.x_cost;
-            const double cost_change = x_cost - cand;
-            if (step_norm <= c.parameter_tolerance * (c.x_norm + c.parameter_tolerance)) {
-                c.done = 1;   // ParameterToleranceReached: return without pushing this record
-                c.termination = VMM_BA_CONVERGENCE;
-            } else if (fabs(cost_change) <= c.function_tolerance * x_cost) {
-                c.cur.cost_change = cost_change;
-                c.done = 1;   // FunctionToleranceReached
-                c.termination = VMM_BA_CONVERGENCE;
-            } else {
-                c.cur.cost_change = cost_change;
-                const double rd = (cand >= DBL_MAX) ? -DBL_MAX : cost_change / mcc;
-                c.cur.relative_decrease = rd;
-                if (rd > c.min_relative_decrease) {
-                    accept = 1;
-                    const double q = 2.0 * rd - 1.0;
-                    double den = 1.0 - q * q * q;
-                    den = den < 1.0 / 3.0 ? 1.0 / 3.0 : den;
-                    double r = c.radius / den;
-                    c.radius = r > c.max_radius ? c.max_radius : r;
-                    c.decrease_factor = 2.0;
-                    c.reuse_diagonal = 0;
-                    c.need_jacobian = 1;     // the blocks evaluated at the candidate become the blocks at x
-                    c.w_which ^= 1;
-                    c.x_norm = sqrt(xn);
-                    c.cur.step_is_successful = 1;
-                } else {
-                    c.cur.step_is_successful = 0;
-                    c.cur.cost = cand;
-                    c.radius = c.radius / c.decrease_factor;
-                    c.decrease_factor *= 2.0;
-                    c.reuse_diagonal = 1;
-                }
-            }
-        }
-        {
-            // phase report.  Order of the groups: evaluation at the candidate (stamp 0) -> k_decide (5) ->
-            // k_iter_begin (1) -> k_form_z (2) -> factorisation (3) -> k_backsub (4) -> next evaluation (0)
-            auto span = [](unsigned long long a, unsigned long long b) { return b > a ? b - a : 0ull; };
-            c.phase_ticks[0] += span(c.stamp[0], t_begin);
-            c.phase_ticks[1] += span(c.stamp[5], c.stamp[2]);
-            c.phase_ticks[2] += span(c.stamp[2], c.stamp[3]);
-            c.phase_ticks[3] += span(c.stamp[3], c.stamp[4]);
-            c.phase_ticks[4] += span(c.stamp[4], c.stamp[0]);
-            c.stamp[5] = t_begin;
-            if (c.done)
-                c.phase_ticks[1] += span(t_begin, __builtin_amdgcn_s_memrealtime());
-        }
-        *ctl = c;
-        s_accept = accept;
-    }
-    __syncthreads();
-    if (s_accept) {
-        for (int i = tid; i < 7 * pv.n_cams; i += 256)
-            pv.cam_qt[i] = pv.cam_cand[i];
-        for (int i = tid; i < 7 * pv.n_tags; i += 256)
-            pv.tag_qt[i] = pv.tag_cand[i];
-    }
-}
-
 // ---- launchers -----------------------------------------------------------------------------------
 
 static PoseViews views(Engine& e)
@@ -615,14 +626,25 @@ static PoseViews views(Engine& e)
     return pv;
 }
 
-void launch_iter_begin(Engine& e, const double* src)
+void launch_control(Engine& e)
 {
     const bool single = !e.multi;
-    // one GPU: nothing to copy (src == dst), the accepted evaluation's blocks are selected through w_which
-    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1024), 0, e.stream, e.ctl, views(e), single ? e.small : src, e.small,
-                       e.small_count, e.H_cam, e.g_cam, e.small_alt_off, e.cost_slot,
-                       single ? e.part_cost : (const double*)nullptr, e.n_e, e.scale,
-                       e.active, e.diag, e.D2, e.trace);
+    DecideArgs dz;
+    dz.pose_part = e.pose_part;
+    dz.cross_slot = e.step_comm + 6 * (size_t)e.n_e;
+    dz.cross_parts = single ? e.part_cross : (const double*)nullptr;
+    dz.n_cross = e.n_e;
+    // candidate cost: one GPU -- the per-pose costs of the evaluation at the candidate, summed in pose order;
+    // world > 1 -- the cost slot of the all-reduced staging copy
+    dz.cand_cost_slot = e.ev_cost;
+    dz.cost_parts = single ? e.part_cost : (const double*)nullptr;
+    dz.n_cost = e.n_e;
+    // one GPU: nothing to copy (src == dst), the accepted evaluation's blocks are selected through w_which;
+    // world > 1: the all-reduced staging copy becomes the working copy
+    hipLaunchKernelGGL(k_control, dim3(1), dim3(1024), 0, e.stream, e.ctl, views(e), dz,
+                       single ? (const double*)e.small : (const double*)e.small_stage, e.small, e.small_count, e.H_cam,
+                       e.g_cam, e.small_alt_off, e.cost_slot, single ? e.part_cost : (const double*)nullptr, e.n_e,
+                       e.scale, e.active, e.diag, e.D2, e.trace);
 }
 
 // One GPU: back-substitution and the candidates of all poses in one launch (launch_candidate is then a no-op).
@@ -654,27 +676,16 @@ void launch_candidate(Engine& e)
                        f_off, e.step_comm, e.yf, e.scale, e.delta, e.H_cam, e.g_cam, e.active, e.pose_part);
 }
 
-void launch_decide(Engine& e)
-{
-    const bool single = !e.multi;
-    // candidate cost: one GPU -- the per-pose costs of the evaluation at the candidate, summed here in pose order;
-    // world > 1 -- the cost slot of the all-reduced staging buffer
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, e.stream, e.ctl, views(e), e.pose_part,
-                       e.step_comm + 6 * (size_t)e.n_e, single ? e.part_cross : (const double*)nullptr, e.n_e,
-                       e.ev_cost, single ? e.part_cost : (const double*)nullptr, e.n_e);
-}
-
 // Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources
 // are known before any launch is recorded into a hipGraph (nothing may be loaded lazily under stream capture).
 int preload_lm_kernels()
 {
     hipFuncAttributes at;
     int bad = 0;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_iter_begin)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_control)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<false>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_candidate)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_decide)) != hipSuccess;
     return bad;
 }
 

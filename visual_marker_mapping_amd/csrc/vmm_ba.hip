@@ -494,8 +494,7 @@ static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg)
         launch_eval_passes(e, false, o.robustify, o.huber_a, true);
         break;
     case 1:
-        launch_decide(e);
-        launch_iter_begin(e, e.small_stage);
+        launch_control(e);
         launch_elim(e);
         launch_syrk_reduced(e);
         launch_pack_lower(e, false);
@@ -1188,7 +1187,7 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
     const int need_cap = std::max(user_cap, 1);
     if (need_cap > e.trace_capacity) {
         int rc;
-        drop_graphs(e);   // the captured k_iter_begin holds the old trace pointer
+        drop_graphs(e);   // the captured k_control holds the old trace pointer
         if (e.trace) {
             HIP_TRY(hipStreamSynchronize(e.stream));
             e.allocs.erase(std::remove(e.allocs.begin(), e.allocs.end(), (void*)e.trace), e.allocs.end());
