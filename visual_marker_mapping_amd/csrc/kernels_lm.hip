@@ -138,8 +138,6 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
                                                  const double* __restrict__ src, double* __restrict__ dst,
                                                  size_t small_count, const double* __restrict__ H0,
                                                  const double* __restrict__ g0, const int64_t alt_off,
-                                                 const double* __restrict__ cost_slot,
-                                                 const double* __restrict__ pose_cost, int n_pose_cost,
                                                  double* __restrict__ scale, int32_t* __restrict__ active,
                                                  double* __restrict__ diag, double* __restrict__ D2,
                                                  vmm_ba_iteration* __restrict__ trace)
@@ -148,28 +146,29 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
         return;
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     __shared__ double sh[256];
-    __shared__ int s_stop, s_reuse, s_evaluated, s_accept, s_need, s_first, s_which, s_done;
-    __shared__ double s_radius, s_lo, s_hi, s_xn, s_gm, s_cst;
+    __shared__ int s_stop, s_reuse, s_accept, s_moved;
+    __shared__ double s_radius, s_lo, s_hi;
     const int tid = threadIdx.x;
     const int n_pose = pv.n_cams + pv.n_tags;
-    // ---- (0) the step decision ----
-    if (ctl->first_eval) {
-        if (tid == 0) {
-            const int which = ctl->w_which ^ 1;   // W and the small blocks at x: what the evaluation just wrote
-            ctl->w_which = which;
-            ctl->phase_ticks[0] += t_begin > ctl->stamp[0] ? t_begin - ctl->stamp[0] : 0ull;
-            ctl->stamp[5] = t_begin;
-            s_accept = 0;
-            s_need = 1;
-            s_first = 1;
-            s_which = which;
-            s_done = 0;
-        }
-    } else {
-        if (tid == 0)
-            s_first = 0;
-        double gd = 0.0, quad = 0.0, sn = 0.0, xn = 0.0, bad = 0.0, cross = 0.0, ccost = 0.0;
-        for (int p = tid; p < n_pose; p += (int)blockDim.x) {
+    const int n_tan = 6 * n_pose;
+    const bool first = ctl->first_eval != 0;
+    const bool jacobi = ctl->jacobi_scaling != 0;
+    const int which = ctl->w_which;     // the copy of W and of the small blocks that belongs to x right now
+    const bool staged = src != dst;     // world > 1: the evaluation went to the all-reduced staging copy
+    // the blocks the evaluation at the candidate has just written
+    const double* __restrict__ nb = staged ? src : dst + (which ? 0 : alt_off);
+    const double* __restrict__ Hn = nb + (H0 - dst);
+    const double* __restrict__ gn = nb + (g0 - dst);
+    // One dependent chain of memory round trips instead of six: everything the decision AND the set-up at an accepted
+    // candidate need is loaded and reduced before the decision is known (the gradient norm and, at iteration zero,
+    // the scaling are properties of the candidate and of its evaluation alone); the control block travels to thread
+    // 0's registers meanwhile and is stored once.
+    __shared__ LmCtl s_c;   // thread 0's working copy (in registers the compiler spills it to scratch)
+    if (tid == 0)
+        s_c = *ctl;
+    double gd = 0.0, quad = 0.0, sn = 0.0, xn = 0.0, bad = 0.0, cross = 0.0, ccost = 0.0, xn0 = 0.0, gm = 0.0;
+    for (int p = tid; p < n_pose; p += (int)blockDim.x) {
+        if (!first) {
             const double* o = dz.pose_part + 5 * (int64_t)p;
             gd += o[0];
             quad += o[1];
@@ -177,27 +176,60 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
             xn += o[3];
             bad = fmax(bad, o[4]);
         }
-        // single GPU: the wave partials of the cross term and of the candidate cost are summed here
-        // (fixed order); with world > 1 they were summed and all-reduced before (scalar slots)
-        if (dz.cross_parts)
-            for (int i = tid; i < dz.n_cross; i += (int)blockDim.x)
-                cross += dz.cross_parts[i];
-        if (dz.cost_parts)
-            for (int i = tid; i < dz.n_cost; i += (int)blockDim.x)
-                ccost += dz.cost_parts[i];
-        double red[7] = { gd, quad, sn, xn, cross, ccost, bad };
-        block_reduce_multi<6, 1>(red, sh);
+        // (a) at the candidate: Jacobi scaling and the reduced program (iteration zero only), gradient max-norm
+        const double* Hp = Hn + 36 * (int64_t)p;
+        int act;
+        if (first) {
+            // blocks with zero Jacobian columns (constant origin tag, poses without observations) are not part of
+            // Ceres' reduced program
+            act = (Hp[0] + Hp[7] + Hp[14]) > 0.0 ? 1 : 0;
+            active[p] = act;
+            for (int k = 0; k < 6; ++k)
+                scale[6 * (int64_t)p + k] = jacobi ? 1.0 / (1.0 + sqrt(Hp[7 * k])) : 1.0;
+        } else {
+            act = active[p];
+        }
+        if (act) {
+            const double* x = pose_ptr(pv, p, true);
+            if (first)
+                for (int k = 0; k < 7; ++k)
+                    xn0 += x[k] * x[k];
+            double ng[6], xp[7];
+            for (int k = 0; k < 6; ++k)
+                ng[k] = -gn[6 * (int64_t)p + k];
+            block_plus(pv, p, x, ng, xp);
+            for (int k = 0; k < 7; ++k)
+                gm = fmax(gm, fabs(x[k] - xp[k]));
+        }
+    }
+    // one GPU: the per-pose partials of the cross term and the per-pose costs of the evaluation at the candidate are
+    // summed here (pose order); world > 1: they were summed and all-reduced before (scalar slots)
+    if (dz.cross_parts && !first)
+        for (int i = tid; i < dz.n_cross; i += (int)blockDim.x)
+            cross += dz.cross_parts[i];
+    if (dz.cost_parts)
+        for (int i = tid; i < dz.n_cost; i += (int)blockDim.x)
+            ccost += dz.cost_parts[i];
+    double red[9] = { gd, quad, sn, xn, cross, ccost, xn0, bad, gm };
+    block_reduce_multi<7, 2>(red, sh);
+    if (tid == 0) {
+        LmCtl& c = s_c;
         gd = red[0];
         quad = red[1];
         sn = red[2];
         xn = red[3];
         cross = dz.cross_parts ? red[4] : dz.cross_slot[0];
         ccost = dz.cost_parts ? red[5] : dz.cand_cost_slot[0];
-        bad = red[6];
-        if (tid == 0) {
-            // one load and one store of the control block: field-by-field global accesses cost ~0.5 us each
-            LmCtl c = *ctl;
-            int accept = 0;
+        xn0 = red[6];
+        bad = red[7];
+        gm = red[8];
+        auto span = [](unsigned long long a, unsigned long long b) { return b > a ? b - a : 0ull; };
+        int accept = 0;
+        // ---- (0) the decision on the step whose candidate was evaluated ----
+        if (first) {
+            c.w_which = which ^ 1;   // W and the small blocks at x: what the evaluation has just written
+            c.phase_ticks[0] += span(c.stamp[0], t_begin);
+        } else {
             const bool lin_fail = c.lin_fail != 0 || bad != 0.0;
             // model_cost_change = -(J d)^T (r + J d / 2) = -d^T g - 1/2 d^T H d   (unscaled coordinates)
             const double mcc = lin_fail ? 0.0 : -gd - 0.5 * (quad + 2.0 * cross);
@@ -249,8 +281,7 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
                         c.radius = r > c.max_radius ? c.max_radius : r;
                         c.decrease_factor = 2.0;
                         c.reuse_diagonal = 0;
-                        c.need_jacobian = 1;     // the blocks evaluated at the candidate become the blocks at x
-                        c.w_which ^= 1;
+                        c.w_which = which ^ 1;   // the blocks evaluated at the candidate become the blocks at x
                         c.x_norm = sqrt(xn);
                         c.cur.step_is_successful = 1;
                     } else {
@@ -262,113 +293,38 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
                     }
                 }
             }
-            {
-                // phase report.  Order of the groups: evaluation at the candidate (stamp 0) -> this kernel (5) ->
-                // k_form_z (2) -> factorisation (3) -> k_backsub (4) -> next evaluation (0)
-                auto span = [](unsigned long long a, unsigned long long b) { return b > a ? b - a : 0ull; };
-                c.phase_ticks[0] += span(c.stamp[0], t_begin);
-                c.phase_ticks[1] += span(c.stamp[5], c.stamp[2]);
-                c.phase_ticks[2] += span(c.stamp[2], c.stamp[3]);
-                c.phase_ticks[3] += span(c.stamp[3], c.stamp[4]);
-                c.phase_ticks[4] += span(c.stamp[4], c.stamp[0]);
-                c.stamp[5] = t_begin;
-                if (c.done)
-                    c.phase_ticks[1] += span(t_begin, __builtin_amdgcn_s_memrealtime());
-            }
-            *ctl = c;
-            s_accept = accept;
-            s_need = c.need_jacobian;
-            s_which = c.w_which;
-            s_done = c.done;
+            // phase report.  Order of the groups: evaluation at the candidate (stamp 0) -> this kernel (5) ->
+            // k_form_z (2) -> factorisation (3) -> k_backsub (4) -> next evaluation (0)
+            c.phase_ticks[0] += span(c.stamp[0], t_begin);
+            c.phase_ticks[1] += span(c.stamp[5], c.stamp[2]);
+            c.phase_ticks[2] += span(c.stamp[2], c.stamp[3]);
+            c.phase_ticks[3] += span(c.stamp[3], c.stamp[4]);
+            c.phase_ticks[4] += span(c.stamp[4], c.stamp[0]);
         }
-    }
-    __syncthreads();
-    if (s_accept) {
-        for (int i = tid; i < 7 * pv.n_cams; i += (int)blockDim.x)
-            pv.cam_qt[i] = pv.cam_cand[i];
-        for (int i = tid; i < 7 * pv.n_tags; i += (int)blockDim.x)
-            pv.tag_qt[i] = pv.tag_cand[i];
-    }
-    if (s_done)
-        return;
-    __syncthreads();   // the new x is in place before (a) reads it
-    // ---- (a), (b), (c) ----
-    const int n_tan = 6 * n_pose;
-    // the copy of the small blocks that belongs to x (an accepted step has just flipped w_which)
-    const double* __restrict__ H = H0 + (s_which ? alt_off : 0);
-    const double* __restrict__ g = g0 + (s_which ? alt_off : 0);
-    if (tid == 0)
-        s_evaluated = 0;
-    __syncthreads();
-    if (s_need) {
-        // multi-GPU: the all-reduced staging buffer becomes the working copy
-        if (src != dst) {
-            for (size_t i = tid; i < small_count; i += blockDim.x)
-                dst[i] = src[i];
-            __syncthreads();
-        }
-        const bool first = s_first != 0;
-        const bool jacobi = ctl->jacobi_scaling != 0;
-        double xn = 0.0, gm = 0.0, cst = 0.0;
-        for (int p = tid; p < n_pose; p += (int)blockDim.x) {
-            const double* Hp = H + 36 * (int64_t)p;
-            if (first) {
-                // blocks with zero Jacobian columns (constant origin tag, poses without observations)
-                // are not part of Ceres' reduced program
-                active[p] = (Hp[0] + Hp[7] + Hp[14]) > 0.0 ? 1 : 0;
-                for (int k = 0; k < 6; ++k)
-                    scale[6 * (int64_t)p + k] = jacobi ? 1.0 / (1.0 + sqrt(Hp[7 * k])) : 1.0;
-            }
-            if (active[p]) {
-                const double* x = pose_ptr(pv, p, false);
-                if (first)
-                    for (int k = 0; k < 7; ++k)
-                        xn += x[k] * x[k];
-                double ng[6], xp[7];
-                for (int k = 0; k < 6; ++k)
-                    ng[k] = -g[6 * (int64_t)p + k];
-                block_plus(pv, p, x, ng, xp);
-                for (int k = 0; k < 7; ++k)
-                    gm = fmax(gm, fabs(x[k] - xp[k]));
-            }
-        }
-        // single GPU: per-pose costs of the eliminated family are summed here; world > 1: cost_slot
-        if (pose_cost)
-            for (int i = tid; i < n_pose_cost; i += (int)blockDim.x)
-                cst += pose_cost[i];
-        double red[3] = { xn, cst, gm };
-        block_reduce_multi<2, 1>(red, sh);
-        s_xn = red[0];
-        s_gm = red[2];
-        s_cst = pose_cost ? red[1] : cost_slot[0];
-        s_evaluated = 1;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        // one load and one store of the control block: field-by-field global accesses cost ~0.5 us each
-        LmCtl c = *ctl;
-        c.stamp[1] = t_begin;
-        if (s_evaluated) {
-            const double cst = s_cst;
-            const bool first = c.first_eval != 0;
+        c.stamp[5] = t_begin;
+        const int moved = (first || accept) ? 1 : 0;
+        // ---- (a) x moved: its cost, gradient norm, and (iteration zero) the start of the trace ----
+        if (!c.done && moved) {
+            const double cst = ccost;
             c.x_cost = cst;
             c.need_jacobian = 0;
             c.num_jac_evals++;
             if (first) {
                 c.first_eval = 0;
                 c.initial_cost = cst;
-                c.x_norm = sqrt(s_xn);
+                c.x_norm = sqrt(xn0);
                 c.cur.iteration = 0;
                 c.cur.step_is_valid = 1;
                 c.cur.step_is_successful = 1;
             }
             c.cur.cost = cst;
-            c.cur.gradient_max_norm = s_gm;
+            c.cur.gradient_max_norm = gm;
             if (!isfinite(cst)) {
                 c.done = 1;
                 c.termination = VMM_BA_FAILURE;
             }
         }
+        // ---- (b) FinalizeIterationAndCheckIfMinimizerCanContinue ----
         int stop = c.done;
         if (!stop) {
             vmm_ba_iteration cur = c.cur;
@@ -412,31 +368,47 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
             }
         }
         s_stop = stop;
+        s_accept = accept;
+        s_moved = moved;
         s_reuse = c.reuse_diagonal;
         s_radius = c.radius;
         s_lo = c.min_lm_diagonal;
         s_hi = c.max_lm_diagonal;
         if (!stop)
             c.reuse_diagonal = 1;
+        else
+            c.phase_ticks[1] += span(t_begin, __builtin_amdgcn_s_memrealtime());
         *ctl = c;
     }
     __syncthreads();
+    if (s_accept) {
+        for (int i = tid; i < 7 * pv.n_cams; i += (int)blockDim.x)
+            pv.cam_qt[i] = pv.cam_cand[i];
+        for (int i = tid; i < 7 * pv.n_tags; i += (int)blockDim.x)
+            pv.tag_qt[i] = pv.tag_cand[i];
+    }
+    // world > 1: the all-reduced staging copy becomes the working copy (one GPU selects through w_which)
+    if (staged && s_moved)
+        for (size_t i = tid; i < small_count; i += blockDim.x)
+            dst[i] = src[i];
     if (s_stop)
         return;
+    // ---- (c) first half of LevenbergMarquardtStrategy::ComputeStep: the LM diagonal ----
+    const double* __restrict__ Hx = s_moved ? Hn : H0 + (which ? alt_off : 0);
     const double lo = s_lo, hi = s_hi;
-    for (int c = tid; c < n_tan; c += (int)blockDim.x) {
+    for (int q = tid; q < n_tan; q += (int)blockDim.x) {
         double d;
         if (!s_reuse) {
-            const int p = c / 6, k = c % 6;
-            const double sc = scale[c];
-            d = sc * sc * H[36 * (int64_t)p + 7 * k];   // squared column norm of the scaled Jacobian
+            const int p = q / 6, k = q % 6;
+            const double sc = scale[q];
+            d = sc * sc * Hx[36 * (int64_t)p + 7 * k];   // squared column norm of the scaled Jacobian
             d = fmin(fmax(d, lo), hi);
-            diag[c] = d;
+            diag[q] = d;
         } else {
-            d = diag[c];
+            d = diag[q];
         }
         const double lm = sqrt(d / s_radius);           // lm_diagonal_ = sqrt(diagonal_ / radius_)
-        D2[c] = lm * lm;
+        D2[q] = lm * lm;
     }
 }
 
@@ -643,8 +615,7 @@ void launch_control(Engine& e)
     // world > 1: the all-reduced staging copy becomes the working copy
     hipLaunchKernelGGL(k_control, dim3(1), dim3(1024), 0, e.stream, e.ctl, views(e), dz,
                        single ? (const double*)e.small : (const double*)e.small_stage, e.small, e.small_count, e.H_cam,
-                       e.g_cam, e.small_alt_off, e.cost_slot, single ? e.part_cost : (const double*)nullptr, e.n_e,
-                       e.scale, e.active, e.diag, e.D2, e.trace);
+                       e.g_cam, e.small_alt_off, e.scale, e.active, e.diag, e.D2, e.trace);
 }
 
 // One GPU: back-substitution and the candidates of all poses in one launch (launch_candidate is then a no-op).
