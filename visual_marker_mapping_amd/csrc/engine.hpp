@@ -171,6 +171,7 @@ struct Engine {
     double* part_cross = nullptr;   // [ordE.n_tasks] cross-term wave partials
     double* part_k1 = nullptr;      // [ordE.n_tasks] candidate-cost wave partials
     double* pose_part = nullptr;    // [n_pose][5] per-pose terms of the step decision
+    double* pose_gm = nullptr;      // [n_pose] per-pose gradient max-norm terms of the evaluation at the candidate
 
     // reprojection statistics (vmm_ba_reprojection_stats): per-task partials, per-pose sums | counts
     double* stats_part = nullptr;   // [n_tasks by camera + n_tasks by tag]

@@ -225,6 +225,11 @@ struct ReduceArgs {
     double* Hout;
     double* gout;
     double* pose_cost;   // or null
+    // LM loop on one GPU: the pose's share of the gradient max-norm |Plus(x, -g) - x|_inf at the evaluated poses
+    // (TrustRegionMinimizer::EvaluateGradientAndJacobian), so that the single-block control kernel only takes a max
+    const double* pose7; // the evaluated poses of this family (7 doubles each), or null
+    int euclid;          // point landmarks: Plus is plain addition of six numbers
+    double* gm_out;      // [n_pose]
 };
 
 // alt_off != 0 (LM loop on one GPU): the blocks go to the copy of the small buffer that does NOT belong to x.
@@ -267,6 +272,30 @@ __global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, const R
         gout[6 * (int64_t)p + (k - 21)] = s;
     } else if (pose_cost) {
         pose_cost[p] = s;
+    }
+    if (r.gm_out) {
+        // the six gradient components sit in lanes 21..26 of the pose's 32-lane group
+        // (rows with p >= n_pose or k >= 28 left above: the shuffles below only read lanes that are here)
+        double ng[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            ng[j] = -__shfl(s, 21 + j, 32);
+        if (k == 21) {
+            const double* x = r.pose7 + 7 * (int64_t)p;
+            double xp[7], gm = 0.0;
+            if (r.euclid) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    xp[j] = x[j] + ng[j];
+                xp[6] = x[6];
+            } else {
+                pose_plus(x, ng, xp);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                gm = fmax(gm, fabs(x[j] - xp[j]));
+            r.gm_out[p] = gm;
+        }
     }
 }
 
@@ -602,6 +631,13 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
     rE.Hout = e_is_cam ? oH_cam : oH_tag;
     rE.gout = e_is_cam ? og_cam : og_tag;
     rE.pose_cost = e.part_cost;   // per-pose cost of the eliminated family
+    const bool want_gm = lm && !e.multi;   // world > 1: the gradient is only complete behind the all-reduce
+    rE.pose7 = want_gm ? (e_is_cam ? e.cam_cand : e.tag_cand) : nullptr;
+    rE.euclid = (e.points && !e_is_cam) ? 1 : 0;
+    rE.gm_out = want_gm ? e.pose_gm + (e_is_cam ? 0 : e.n_cams) : nullptr;
+    rF.pose7 = want_gm ? (e_is_cam ? e.tag_cand : e.cam_cand) : nullptr;
+    rF.euclid = (e.points && e_is_cam) ? 1 : 0;
+    rF.gm_out = want_gm ? e.pose_gm + (e_is_cam ? e.n_cams : 0) : nullptr;
     rF.n_pose = e.n_f;
     rF.pose_task = e.ordF.pose_task;
     rF.part = e.ordF.part;

@@ -9,77 +9,60 @@
 
 namespace vmm {
 
-__device__ __forceinline__ double block_sum(double v, double* sh)
-{
-    const int tid = threadIdx.x;
-    sh[tid] = v;
-    __syncthreads();
-    for (int m = blockDim.x / 2; m >= 1; m >>= 1) {
-        if (tid < m)
-            sh[tid] += sh[tid + m];
-        __syncthreads();
-    }
-    const double r = sh[0];
-    __syncthreads();
-    return r;
-}
-
-__device__ __forceinline__ double block_max(double v, double* sh)
-{
-    const int tid = threadIdx.x;
-    sh[tid] = v;
-    __syncthreads();
-    for (int m = blockDim.x / 2; m >= 1; m >>= 1) {
-        if (tid < m)
-            sh[tid] = fmax(sh[tid], sh[tid + m]);
-        __syncthreads();
-    }
-    const double r = sh[0];
-    __syncthreads();
-    return r;
-}
-
-// Sums (and maxes) several per-thread values over the block with ONE barrier: wave butterflies, then every
-// thread combines the wave totals in a fixed order (pairwise for 4 waves, wave order otherwise).  v[0..NS) are
-// summed, v[NS..NS+NM) are maxed; every thread returns with the block totals in v.  Deterministic.
-// sh: [blockDim.x / 64][NS + NM].
-template <int NS, int NM>
-__device__ __forceinline__ void block_reduce_multi(double (&v)[NS + NM], double* sh)
+// The control kernel's reduction: seven sums and two maxima over the block, needed by thread 0 only.
+// One shared butterfly per wave (the number of live values halves while the span doubles: 10 + 6 lane exchanges
+// instead of 9 x 6), wave totals to LDS, ONE barrier, and thread 0 adds the wave totals in wave order; nobody else
+// reads them (sixteen waves each reading all of them was 4 us of LDS instructions on one compute unit).
+// v[0..6] sums, v[7] must be 0, m[0..1] maxima (>= 0).  sh: [waves][10].  Result valid in thread 0.  Deterministic.
+__device__ __forceinline__ void control_reduce(double (&v)[8], double (&m)[2], double* sh)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = blockDim.x >> 6;
 #pragma unroll
-    for (int k = 0; k < NS; ++k)
-        v[k] = wave_sum(v[k]);
+    for (int level = 0; level < 3; ++level) {
+        const int off = 32 >> level;
+        const bool hi = (lane & off) != 0;
 #pragma unroll
-    for (int k = NS; k < NS + NM; ++k) {
-#pragma unroll
-        for (int mk = 32; mk >= 1; mk >>= 1)
-            v[k] = fmax(v[k], __shfl_xor(v[k], mk, 64));
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < NS + NM; ++k)
-            sh[wave * (NS + NM) + k] = v[k];
-    }
-    __syncthreads();
-    if (nw == 4) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k)
-            v[k] = (sh[k] + sh[(NS + NM) + k]) + (sh[2 * (NS + NM) + k] + sh[3 * (NS + NM) + k]);
-#pragma unroll
-        for (int k = NS; k < NS + NM; ++k)
-            v[k] = fmax(fmax(sh[k], sh[(NS + NM) + k]), fmax(sh[2 * (NS + NM) + k], sh[3 * (NS + NM) + k]));
-    } else {
-#pragma unroll
-        for (int k = 0; k < NS + NM; ++k) {
-            double r = sh[k];
-            for (int w = 1; w < nw; ++w)
-                r = (k < NS) ? r + sh[w * (NS + NM) + k] : fmax(r, sh[w * (NS + NM) + k]);
-            v[k] = r;
+        for (int j = 0; j < (4 >> level); ++j) {
+            const double keep = hi ? v[2 * j + 1] : v[2 * j];
+            const double send = hi ? v[2 * j] : v[2 * j + 1];
+            v[j] = keep + __shfl_xor(send, off, 64);
         }
     }
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1)
+        v[0] += __shfl_xor(v[0], off, 64);
+    {
+        const bool hi = (lane & 32) != 0;
+        const double keep = hi ? m[1] : m[0];
+        const double send = hi ? m[0] : m[1];
+        m[0] = fmax(keep, __shfl_xor(send, 32, 64));
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1)
+            m[0] = fmax(m[0], __shfl_xor(m[0], off, 64));
+    }
+    // value index a lane ends with: bit 0 from lane bit 5, bit 1 from lane bit 4, bit 2 from lane bit 3
+    if ((lane & 7) == 0)
+        sh[wave * 10 + (((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2))] = v[0];
+    if ((lane & 31) == 0)
+        sh[wave * 10 + 8 + (lane >> 5)] = m[0];
     __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double r = sh[k];
+            for (int w = 1; w < nw; ++w)
+                r += sh[w * 10 + k];
+            v[k] = r;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double r = sh[8 + k];
+            for (int w = 1; w < nw; ++w)
+                r = fmax(r, sh[w * 10 + 8 + k]);
+            m[k] = r;
+        }
+    }
 }
 
 struct PoseViews {
@@ -124,6 +107,21 @@ __device__ __forceinline__ double* pose_ptr(const PoseViews& v, int p, bool cand
 //  (c) first half of LevenbergMarquardtStrategy::ComputeStep: the LM diagonal D^2.
 // (Two kernels until the evaluation moved to the candidate put them next to each other; one launch saves the
 // dependent-launch gap and a second read-modify-write of the control block.)
+#ifdef VMM_STAMPS
+__device__ unsigned long long g_ctl_stamps[16];
+#define CTL_RT(slot)                                                    \
+    do {                                                                \
+        if (threadIdx.x == 0)                                           \
+            g_ctl_stamps[slot] = __builtin_amdgcn_s_memrealtime();      \
+    } while (0)
+extern "C" int vmm_ba_debug_read_ctl_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ctl_stamps), sizeof(unsigned long long) * 16);
+}
+#else
+#define CTL_RT(slot)
+#endif
+
 struct DecideArgs {
     const double* pose_part;        // [n_pose][5], k_backsub / k_candidate
     const double* cross_slot;       // world > 1: all-reduced cross term
@@ -132,6 +130,7 @@ struct DecideArgs {
     const double* cand_cost_slot;   // world > 1: cost slot of the all-reduced staging copy
     const double* cost_parts;       // one GPU: per-pose costs of the evaluation at the candidate
     int n_cost;
+    const double* pose_gm;          // one GPU: per-pose |Plus(x+, -g) - x+|_inf from k_reduce_pose; null: computed here
 };
 
 __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, const DecideArgs dz,
@@ -145,6 +144,7 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
     if (ctl->done)
         return;
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    CTL_RT(0);
     __shared__ double sh[256];
     __shared__ int s_stop, s_reuse, s_accept, s_moved;
     __shared__ double s_radius, s_lo, s_hi;
@@ -194,12 +194,18 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
             if (first)
                 for (int k = 0; k < 7; ++k)
                     xn0 += x[k] * x[k];
-            double ng[6], xp[7];
-            for (int k = 0; k < 6; ++k)
-                ng[k] = -gn[6 * (int64_t)p + k];
-            block_plus(pv, p, x, ng, xp);
-            for (int k = 0; k < 7; ++k)
-                gm = fmax(gm, fabs(x[k] - xp[k]));
+            if (dz.pose_gm) {
+                gm = fmax(gm, dz.pose_gm[p]);
+            } else {
+                // 700 quaternion exponentials on one compute unit cost ~8 us: only where the gradient is not
+                // known before this kernel (world > 1: behind the all-reduce)
+                double ng[6], xp[7];
+                for (int k = 0; k < 6; ++k)
+                    ng[k] = -gn[6 * (int64_t)p + k];
+                block_plus(pv, p, x, ng, xp);
+                for (int k = 0; k < 7; ++k)
+                    gm = fmax(gm, fabs(x[k] - xp[k]));
+            }
         }
     }
     // one GPU: the per-pose partials of the cross term and the per-pose costs of the evaluation at the candidate are
@@ -210,8 +216,11 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
     if (dz.cost_parts)
         for (int i = tid; i < dz.n_cost; i += (int)blockDim.x)
             ccost += dz.cost_parts[i];
-    double red[9] = { gd, quad, sn, xn, cross, ccost, xn0, bad, gm };
-    block_reduce_multi<7, 2>(red, sh);
+    CTL_RT(1);
+    double red[8] = { gd, quad, sn, xn, cross, ccost, xn0, 0.0 };
+    double redm[2] = { bad, gm };
+    control_reduce(red, redm, sh);
+    CTL_RT(2);
     if (tid == 0) {
         LmCtl& c = s_c;
         gd = red[0];
@@ -221,8 +230,8 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
         cross = dz.cross_parts ? red[4] : dz.cross_slot[0];
         ccost = dz.cost_parts ? red[5] : dz.cand_cost_slot[0];
         xn0 = red[6];
-        bad = red[7];
-        gm = red[8];
+        bad = redm[0];
+        gm = redm[1];
         auto span = [](unsigned long long a, unsigned long long b) { return b > a ? b - a : 0ull; };
         int accept = 0;
         // ---- (0) the decision on the step whose candidate was evaluated ----
@@ -378,9 +387,12 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
             c.reuse_diagonal = 1;
         else
             c.phase_ticks[1] += span(t_begin, __builtin_amdgcn_s_memrealtime());
+        CTL_RT(3);
         *ctl = c;
+        CTL_RT(4);
     }
     __syncthreads();
+    CTL_RT(5);
     if (s_accept) {
         for (int i = tid; i < 7 * pv.n_cams; i += (int)blockDim.x)
             pv.cam_qt[i] = pv.cam_cand[i];
@@ -410,6 +422,7 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
         const double lm = sqrt(d / s_radius);           // lm_diagonal_ = sqrt(diagonal_ / radius_)
         D2[q] = lm * lm;
     }
+    CTL_RT(6);
 }
 
 // One pose's share of TrustRegionMinimizer::ComputeCandidatePointAndEvaluateCost (first half): the unscaled tangent
@@ -611,6 +624,7 @@ void launch_control(Engine& e)
     dz.cand_cost_slot = e.ev_cost;
     dz.cost_parts = single ? e.part_cost : (const double*)nullptr;
     dz.n_cost = e.n_e;
+    dz.pose_gm = single ? e.pose_gm : (const double*)nullptr;
     // one GPU: nothing to copy (src == dst), the accepted evaluation's blocks are selected through w_which;
     // world > 1: the all-reduced staging copy becomes the working copy
     hipLaunchKernelGGL(k_control, dim3(1), dim3(1024), 0, e.stream, e.ctl, views(e), dz,

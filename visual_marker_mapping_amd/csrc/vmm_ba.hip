@@ -1005,6 +1005,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.part_cross, n_part))) return fail(rc);
     if ((rc = dev_alloc(e, &e.part_k1, n_part))) return fail(rc);
     if ((rc = dev_alloc(e, &e.pose_part, (size_t)5 * n_pose))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.pose_gm, (size_t)n_pose))) return fail(rc);
     if ((rc = dev_alloc(e, &e.ctl, 1))) return fail(rc);
     if (hipHostMalloc((void**)&e.ctl_host, sizeof(LmCtl)) != hipSuccess) {
         set_error("hipHostMalloc failed");
