@@ -167,10 +167,13 @@ def main():
         kern = {
             # algorithmic bytes per tag observation: SURVEY.md 8(d) -- 360 B for the fused
             # residual+Jacobian+accumulate evaluation (72 B in + one f64 6x6 W block out), 72 B cost-only.
-            # Timed as the iteration runs it: k_eval_both (both family passes) + k_reduce_pose, two launches.
+            # Timed as the iteration runs it: k_eval_both (both family passes) + k_reduce_pose, two launches; since
+            # round 2 this is the ONLY evaluation of an LM iteration (at the candidate: its cost decides the step,
+            # its blocks are the next iteration's when the step is accepted).
             "eval_jacobian": {"ms": kt["eval_elim_ms"] + kt["eval_keep_ms"], "bound": "hbm",
                               "alg": (360.0 if precision == "f64" else 216.0) * n_obs, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s"},
+            # cost-only pass (vmm_ba_cost): no longer part of an LM iteration, reported for its HBM roofline
             "eval_cost": {"ms": kt["cost_ms"], "bound": "hbm", "alg": 72.0 * n_obs, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s"},
             # S = Z^T Z, lower triangle incl. the rhs row: (n+1)(n+2)/2 * K multiply-adds
