@@ -17,7 +17,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, elim):
+FAR = dict(n_cams=20, n_tags=10, cam_rot_deg=50.0, cam_trans_m=0.8, tag_rot_deg=50.0, tag_trans_m=0.5)   # rejected steps
+
+
+def _scene(far):
+    from visual_marker_mapping_amd.synthetic import make_scene
+    return make_scene(1, **FAR) if far else make_scene(1, visibility=0.7)
+
+
+def _worker(rank, world, port, out, elim, far=False):
     import torch
     import torch.distributed as dist
     from visual_marker_mapping_amd import distributed as vd
@@ -25,44 +33,50 @@ def _worker(rank, world, port, out, elim):
     from visual_marker_mapping_amd.synthetic import make_scene
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    s = make_scene(1, visibility=0.7)
+    s = _scene(far)
     elim_cams = (elim == "cams")
     idx, _ = vd.shard_observations(s.obs_cam, s.obs_tag, len(s.cam_init), len(s.tag_init), rank, world, elim_cams)
     ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam[idx],
                             s.obs_tag[idx], s.obs_px[idx], device=0,
                             elimination=eng.ELIM_CAMERAS if elim_cams else eng.ELIM_TAGS, rank=rank, world_size=world)
     ba.set_allreduce(vd.make_allreduce(0))
-    out_s = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+    out_s = ba.solve(eng.default_options(robustify=0 if far else 1), trace_capacity=128)
     cam, tag = ba.get_state()
-    cost = ba.cost(robustify=True)
+    cost = ba.cost(robustify=not far)
     ba.close()
     np.savez(out % rank, cam=cam, tag=tag, iters=out_s["iterations"], final=out_s["final_cost"], cost=cost,
-             costs=[t["cost"] for t in out_s["trace"]])
+             costs=[t["cost"] for t in out_s["trace"]], ok=[t["step_is_successful"] for t in out_s["trace"]])
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("elim", ["cams", "tags"])
-def test_two_ranks_match_one_rank(tmp_path, elim):
+@pytest.mark.parametrize("elim,far", [("cams", False), ("tags", False), ("cams", True)])
+def test_two_ranks_match_one_rank(tmp_path, elim, far):
+    """far: a start 50 degrees / 0.8 m off, several consecutive rejected steps -- the all-reduced evaluation at a
+    rejected candidate must be dropped on every rank alike."""
     mp = pytest.importorskip("torch.multiprocessing")
     from visual_marker_mapping_amd import engine as eng
-    from visual_marker_mapping_amd.synthetic import make_scene
     out = str(tmp_path / "rank%d.npz")
-    mp.spawn(_worker, args=(2, _free_port(), out, elim), nprocs=2, join=True)
-    s = make_scene(1, visibility=0.7)
+    mp.spawn(_worker, args=(2, _free_port(), out, elim, far), nprocs=2, join=True)
+    s = _scene(far)
     ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
                             s.obs_px, elimination=eng.ELIM_CAMERAS if elim == "cams" else eng.ELIM_TAGS)
-    ref = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+    ref = ba.solve(eng.default_options(robustify=0 if far else 1), trace_capacity=128)
     cam, tag = ba.get_state()
     ba.close()
     r0, r1 = np.load(out % 0), np.load(out % 1)
+    if far:
+        assert ref["num_unsuccessful_steps"] >= 2 and ref["termination_type"] == eng.CONVERGENCE
+    np.testing.assert_array_equal(r0["ok"], [t["step_is_successful"] for t in ref["trace"]])
     # both ranks hold the same full state, equal to the single-rank result (SURVEY.md section 4: <= 1e-12 rel.)
     np.testing.assert_array_equal(r0["cam"], r1["cam"])
     np.testing.assert_array_equal(r0["tag"], r1["tag"])
     assert int(r0["iters"]) == ref["iterations"]
-    np.testing.assert_allclose(r0["costs"], [t["cost"] for t in ref["trace"]], rtol=1e-10)
-    np.testing.assert_allclose(r0["cam"], cam, rtol=0, atol=1e-10 * np.abs(cam).max())
-    np.testing.assert_allclose(r0["tag"], tag, rtol=0, atol=1e-10 * np.abs(tag).max())
+    # far: costs of 1e9 on a trajectory through rejected steps amplify the different summation order of two shards
+    tol = 1e-7 if far else 1e-10
+    np.testing.assert_allclose(r0["costs"], [t["cost"] for t in ref["trace"]], rtol=tol)
+    np.testing.assert_allclose(r0["cam"], cam, rtol=0, atol=tol * np.abs(cam).max())
+    np.testing.assert_allclose(r0["tag"], tag, rtol=0, atol=tol * np.abs(tag).max())
     np.testing.assert_allclose(float(r0["cost"]), float(r0["final"]), rtol=1e-12)
 
 

@@ -249,3 +249,34 @@ def test_phase_report_accounts_for_the_solve():
     n = out["num_lm_iterations"]
     assert 50e-6 * n < out["time_factor_solve_s"] < 1e-3 * n   # the Cholesky dominates: 0.2-0.3 ms per iteration
     assert out["time_eval_s"] < out["time_factor_solve_s"]
+
+
+@pytest.mark.parametrize("elim", ["cams", "tags"])
+def test_rejected_steps_match_oracle(oracle, elim):
+    """A start far from the optimum (50 degrees / 0.8 m off): the trust region has to shrink through several
+    consecutive REJECTED steps before the solve converges.  Every LM iteration evaluates at the candidate; a rejected
+    candidate's blocks and W must be dropped (LmCtl::w_which unchanged), the diagonal reused, the radius divided --
+    the trace has to follow the oracle's through the rejections, and the converged poses have to agree."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=20, n_tags=10, cam_rot_deg=50.0, cam_trans_m=0.8, tag_rot_deg=50.0, tag_trans_m=0.5)
+    sc = oracle.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+    summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, num_threads=4, linear_solver=oracle.DENSE_NORMAL))
+    assert summ["num_unsuccessful_steps"] >= 3 and summ["termination_type"] == 0
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                            s.obs_px, elimination=eng.ELIM_CAMERAS if elim == "cams" else eng.ELIM_TAGS)
+    try:
+        out = ba.solve(eng.default_options(robustify=0), trace_capacity=128)
+        cam, tag = ba.get_state()
+        # the same handle again: the second solve starts from w_which = 0 whatever the first one left
+        ba.set_state(s.cam_init, s.tag_init)
+        out2 = ba.solve(eng.default_options(robustify=0), trace_capacity=128)
+        cam2, tag2 = ba.get_state()
+    finally:
+        ba.close()
+    _assert_same_trace(out, summ, trace, rtol=1e-6)
+    assert [t["step_is_successful"] for t in out["trace"]].count(0) == summ["num_unsuccessful_steps"]
+    _assert_same_solution(cam, tag, sc, s.tag_wh)
+    assert out2["iterations"] == out["iterations"] and out2["final_cost"] == out["final_cost"]
+    np.testing.assert_array_equal(cam2, cam)
+    np.testing.assert_array_equal(tag2, tag)

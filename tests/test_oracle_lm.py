@@ -146,3 +146,32 @@ def test_point_landmark_zero_noise_recovers_the_corners(oracle):
     _, gt = _point_scene(oracle, s, init=False)
     assert summ["final_cost"] < 1e-10
     np.testing.assert_allclose(oracle.scene_points(sc), gt, rtol=0, atol=1e-8)
+
+
+def test_rejected_steps_follow_ceres_policy(oracle):
+    """A start 50 degrees / 0.8 m off the optimum: the trust region shrinks through consecutive rejected steps.
+    TrustRegionMinimizer semantics on that path (Appendix A.4): a rejected step leaves x, the cost and the gradient
+    norm untouched, divides the radius by a factor that doubles with every consecutive rejection (2, 4, 8, ...), and
+    the next accepted step resets the factor; the three exact linear solvers take the same decisions."""
+    s = make_scene(1, n_cams=20, n_tags=10, cam_rot_deg=50.0, cam_trans_m=0.8, tag_rot_deg=50.0, tag_trans_m=0.5)
+    runs = []
+    for solver in (oracle.DENSE_NORMAL, oracle.SCHUR_ELIM_TAGS, oracle.SCHUR_ELIM_CAMS):
+        sc = _scene(oracle, s)
+        summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, linear_solver=solver))
+        assert summ["termination_type"] == oracle.CONVERGENCE and summ["num_unsuccessful_steps"] >= 3
+        runs.append((summ, trace))
+    summ, trace = runs[0]
+    for other, tr in runs[1:]:
+        assert other["iterations"] == summ["iterations"]
+        assert [t["step_is_successful"] for t in tr] == [t["step_is_successful"] for t in trace]
+        np.testing.assert_allclose([t["cost"] for t in tr], [t["cost"] for t in trace], rtol=1e-7)
+    factor = 2.0
+    for prev, cur in zip(trace, trace[1:]):
+        if cur["step_is_successful"]:
+            assert cur["cost"] < prev["cost"] or not prev["step_is_successful"]
+            factor = 2.0
+        else:
+            # a row carries the radius AFTER its step's accept / reject update (IterationSummary::trust_region_radius)
+            np.testing.assert_allclose(cur["trust_region_radius"], prev["trust_region_radius"] / factor, rtol=1e-12)
+            factor *= 2.0
+            assert cur["gradient_max_norm"] == prev["gradient_max_norm"]
