@@ -266,6 +266,11 @@ int vmm_ba_dense_spd_solve(int device, int n, const double* A, const double* b, 
  * the engine's MFMA kernel. */
 int vmm_ba_dense_syrk(int device, int k, int n, const double* Z, double* C);
 
+/* Test/diagnostic: out[i] = Plus(qt[i], delta[i]) for n poses (7 doubles each, tangent 6 each) with the engine's own
+ * device function -- QuaternionParameterization::Plus on the rotation, plain addition on the translation
+ * (src/TagReconstructor.cpp:665-666,692-693 attach it to every q block; tangent order: translation, rotation). */
+int vmm_ba_pose_plus(int64_t n, const double* qt, const double* delta, double* out, int device);
+
 /* Times each kernel of an LM iteration at the current state (reps launches each). */
 int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vmm_ba_kernel_times* out);
 

@@ -247,3 +247,14 @@ print("stamps build ok")
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          universal_newlines=True, timeout=300)
     assert out.returncode == 0 and "stamps build ok" in out.stdout, out.stdout
+
+
+def test_pose_plus_matches_mpmath(eng, kats):
+    """QuaternionParameterization::Plus (a5) on the device, directly against the 50-digit KATs -- until now the GPU's
+    Plus was only pinned through whole trajectories."""
+    qt = np.array([c["qt"] for c in kats["plus"]])
+    delta = np.array([c["delta"] for c in kats["plus"]])
+    ref = np.array([c["out"] for c in kats["plus"]])
+    np.testing.assert_allclose(eng.pose_plus(qt, delta), ref, rtol=0, atol=4e-15)
+    # a zero step is the identity, bit for bit (the LM loop relies on Plus(x, 0) == x for switched-off poses)
+    np.testing.assert_array_equal(eng.pose_plus(qt, np.zeros_like(delta)), qt)

@@ -234,6 +234,7 @@ void launch_cov_trsm(Engine& e, double* B, int ldb, int n_chunks, bool identity_
 void launch_cov_gram(Engine& e, const double* X, int ldb, double* cov_dev);
 // kernels_lm.hip
 void launch_control(Engine& e);
+void launch_pose_plus(hipStream_t st, int64_t n, const double* qt, const double* delta, double* out);
 void launch_backsub(Engine& e);
 void launch_candidate(Engine& e);
 

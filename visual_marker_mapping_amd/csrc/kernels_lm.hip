@@ -596,6 +596,28 @@ __global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_p
     candidate_for_pose(pv, p, d, delta, H, g, active, pose_part);
 }
 
+// Diagnostic (vmm_ba_pose_plus): the Plus the LM loop applies, on caller-supplied poses and tangent steps.
+__global__ void k_pose_plus(int64_t n, const double* __restrict__ qt, const double* __restrict__ delta,
+                            double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double x[7], d[6], o[7];
+    for (int k = 0; k < 7; ++k)
+        x[k] = qt[7 * i + k];
+    for (int k = 0; k < 6; ++k)
+        d[k] = delta[6 * i + k];
+    pose_plus(x, d, o);
+    for (int k = 0; k < 7; ++k)
+        out[7 * i + k] = o[k];
+}
+
+void launch_pose_plus(hipStream_t st, int64_t n, const double* qt, const double* delta, double* out)
+{
+    hipLaunchKernelGGL(k_pose_plus, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, qt, delta, out);
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 
 static PoseViews views(Engine& e)

@@ -1430,6 +1430,32 @@ int vmm_ba_project_points(const double intr[4], const double dist[5], int64_t n,
     return VMM_BA_OK;
 }
 
+int vmm_ba_pose_plus(int64_t n, const double* qt, const double* delta, double* out, int device)
+{
+    if (n < 0 || (n > 0 && (!qt || !delta || !out))) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    if (n == 0)
+        return VMM_BA_OK;
+    HIP_TRY(hipSetDevice(device));
+    double* d = nullptr;   // qt | delta | out
+    HIP_TRY(hipMalloc((void**)&d, sizeof(double) * 20 * n));
+    hipError_t err = hipMemcpy(d, qt, sizeof(double) * 7 * n, hipMemcpyHostToDevice);
+    if (err == hipSuccess)
+        err = hipMemcpy(d + 7 * n, delta, sizeof(double) * 6 * n, hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        launch_pose_plus(nullptr, n, d, d + 7 * n, d + 13 * n);
+        err = hipMemcpy(out, d + 13 * n, sizeof(double) * 7 * n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (err != hipSuccess) {
+        set_error(std::string("pose_plus: ") + hipGetErrorString(err));
+        return VMM_BA_ERR_HIP;
+    }
+    return VMM_BA_OK;
+}
+
 int vmm_ba_eval_blocks(vmm_ba_handle h, int robustify, double huber_a, double* cost, double* V, double* U,
                        double* W, double* g_cam, double* g_tag)
 {

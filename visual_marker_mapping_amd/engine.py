@@ -200,6 +200,16 @@ def project_points(intr, dist, points_cam, device=0):
     return uv
 
 
+def pose_plus(qt, delta, device=0):
+    """Plus(qt, delta) for (n,7) poses and (n,6) tangent steps with the engine's device function
+    (Ceres QuaternionParameterization::Plus on q, addition on t; tangent = translation then rotation)."""
+    qt = np.ascontiguousarray(qt, np.float64).reshape(-1, 7)
+    delta = np.ascontiguousarray(delta, np.float64).reshape(-1, 6)
+    out = np.zeros_like(qt)
+    _lib.check(_lib.lib().vmm_ba_pose_plus(len(qt), _ptr(qt), _ptr(delta), _ptr(out), device))
+    return out
+
+
 def dense_spd_solve(A, b, device=0):
     A = np.ascontiguousarray(A, np.float64)
     b = np.ascontiguousarray(b, np.float64)
