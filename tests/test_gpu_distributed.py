@@ -1,5 +1,5 @@
 """Two ranks (one process each, both on the single test GPU, gloo for the exchange) must follow the
-same LM trajectory as one rank: the sharded engine path with its four all-reduces per iteration."""
+same LM trajectory as one rank: the sharded engine path with its three all-reduces per iteration."""
 import os
 import socket
 
