@@ -53,7 +53,6 @@ struct LmCtl {
     // minimizer
     double x_cost, cand_cost, model_cost_change, x_norm, initial_cost;
     int32_t iteration;         // index of the iteration record being built
-    int32_t need_jacobian;     // the evaluation at the candidate was accepted: its blocks become the blocks at x
     int32_t first_eval;        // the pending evaluation is iteration zero
     int32_t done, termination;
     int32_t lin_fail;          // a Cholesky pivot was not positive in this iteration
@@ -207,8 +206,7 @@ int preload_cov_kernels();
 
 // ---- kernel launchers (defined in the .hip files) ----
 // kernels_eval.hip
-void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, double huber_a, bool use_ctl);
-void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bool use_ctl);
+void launch_eval_passes(Engine& e, int robustify, double huber_a, bool use_ctl);
 void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a);
 void launch_cost(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a,
                  double* out_scalar);

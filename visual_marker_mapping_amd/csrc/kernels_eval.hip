@@ -35,8 +35,7 @@ struct EvalArgs {
     void* W_alt;               // LM loop: the evaluation at the candidate writes the buffer LmCtl::w_which does NOT name
     const int32_t* caller;     // position of each sorted observation in the caller's order
     const uint8_t* mask;       // [n_obs] caller order: 0 = observation switched off (vmm_ba_set_observation_mask)
-    const LmCtl* ctl;          // null: always run
-    int guard_need_jacobian;
+    const LmCtl* ctl;          // LM loop: returns at once when the loop is over; null: always run
 };
 
 __device__ __forceinline__ int tri(int a, int b) { return a * (a + 1) / 2 + b; }
@@ -185,20 +184,6 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
         a.part[(int64_t)wave * kPart + slot] = mine;
 }
 
-template <bool OWN_IS_CAM, bool WRITE_W, typename AT = double, bool POINTS = false>
-__global__ __launch_bounds__(256) void k_eval(const EvalArgs a)
-{
-    if (a.ctl) {
-        if (a.ctl->done)
-            return;
-        if (a.guard_need_jacobian && !a.ctl->need_jacobian)
-            return;
-        if (WRITE_W)
-            phase_stamp(a.ctl, 0);
-    }
-    eval_body<OWN_IS_CAM, WRITE_W, AT, POINTS>(a, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-}
-
 // Both family passes in one launch: workgroups [0, nb_e) run the pass over the eliminated family (writes W),
 // the rest the pass over the kept family.  The passes are independent, so they share the chip.
 template <bool E_IS_CAM, typename AT = double, bool POINTS = false>
@@ -206,8 +191,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 {
     if (aE.ctl) {
         if (aE.ctl->done)
-            return;
-        if (aE.guard_need_jacobian && !aE.ctl->need_jacobian)
             return;
         phase_stamp(aE.ctl, 0);
     }
@@ -233,14 +216,11 @@ struct ReduceArgs {
 };
 
 // alt_off != 0 (LM loop on one GPU): the blocks go to the copy of the small buffer that does NOT belong to x.
-__global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, const ReduceArgs rE, const ReduceArgs rF,
-                              const int64_t alt_off)
+__global__ void k_reduce_pose(const LmCtl* ctl, const ReduceArgs rE, const ReduceArgs rF, const int64_t alt_off)
 {
     int64_t off = 0;
     if (ctl) {
         if (ctl->done)
-            return;
-        if (guard_need_jacobian && !ctl->need_jacobian)
             return;
         off = ctl->w_which ? 0 : alt_off;
     }
@@ -300,16 +280,11 @@ __global__ void k_reduce_pose(const LmCtl* ctl, int guard_need_jacobian, const R
 }
 
 // out[0] = sum_{i<n} in[i*stride] in a fixed order (one block, pairwise tree over a serial prefix).
-__global__ __launch_bounds__(256) void k_sum(const LmCtl* ctl, int guard_need_jacobian,
-                                             const double* __restrict__ in, int n, int stride,
+__global__ __launch_bounds__(256) void k_sum(const LmCtl* ctl, const double* __restrict__ in, int n, int stride,
                                              double* __restrict__ out)
 {
-    if (ctl) {
-        if (ctl->done)
-            return;
-        if (guard_need_jacobian && !ctl->need_jacobian)
-            return;
-    }
+    if (ctl && ctl->done)
+        return;
     __shared__ double sh[256];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256)
@@ -507,7 +482,7 @@ __global__ void k_project(Intrinsics K, int64_t n, const double* __restrict__ pc
 static inline int blocks_for_tasks(int n_tasks) { return (n_tasks + 3) / 4; }
 
 // lm: the evaluation of the LM loop -- at the candidate poses, W into the buffer LmCtl::w_which does not name
-static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, void* W, bool guard, bool lm = false)
+static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, void* W, bool lm = false)
 {
     EvalArgs a;
     a.K = e.K;
@@ -531,70 +506,18 @@ static EvalArgs make_eval_args(Engine& e, const ObsOrder& ord, bool own_is_cam, 
     a.caller = ord.caller;
     a.mask = e.obs_mask;
     a.ctl = e.ctl;
-    a.guard_need_jacobian = guard ? 1 : 0;
     return a;
 }
 
-void launch_eval_pass(Engine& e, bool elim_family, bool guard, int robustify, double huber_a, bool use_ctl)
-{
-    const bool e_is_cam = e.elim_cams;
-    const bool own_is_cam = elim_family ? e_is_cam : !e_is_cam;
-    EvalArgs a = make_eval_args(e, elim_family ? e.ordE : e.ordF, own_is_cam, elim_family ? (e.f32_accum ? (void*)e.Wf : (void*)e.W) : nullptr, guard);
-    a.robustify = robustify;
-    a.huber_a = huber_a;
-    if (!use_ctl)
-        a.ctl = nullptr;
-    if (a.n_tasks <= 0)
-        return;
-    const dim3 grid(blocks_for_tasks(a.n_tasks)), block(256);
-    if (e.points) {   // f64 only (vmm_ba_create refuses the combination with f32 accumulation)
-        if (elim_family) {
-            if (own_is_cam)
-                hipLaunchKernelGGL((k_eval<true, true, double, true>), grid, block, 0, e.stream, a);
-            else
-                hipLaunchKernelGGL((k_eval<false, true, double, true>), grid, block, 0, e.stream, a);
-        } else {
-            if (own_is_cam)
-                hipLaunchKernelGGL((k_eval<true, false, double, true>), grid, block, 0, e.stream, a);
-            else
-                hipLaunchKernelGGL((k_eval<false, false, double, true>), grid, block, 0, e.stream, a);
-        }
-    } else if (e.f32_accum) {
-        if (elim_family) {
-            if (own_is_cam)
-                hipLaunchKernelGGL((k_eval<true, true, float>), grid, block, 0, e.stream, a);
-            else
-                hipLaunchKernelGGL((k_eval<false, true, float>), grid, block, 0, e.stream, a);
-        } else {
-            if (own_is_cam)
-                hipLaunchKernelGGL((k_eval<true, false, float>), grid, block, 0, e.stream, a);
-            else
-                hipLaunchKernelGGL((k_eval<false, false, float>), grid, block, 0, e.stream, a);
-        }
-    } else if (elim_family) {
-        if (own_is_cam)
-            hipLaunchKernelGGL((k_eval<true, true>), grid, block, 0, e.stream, a);
-        else
-            hipLaunchKernelGGL((k_eval<false, true>), grid, block, 0, e.stream, a);
-    } else {
-        if (own_is_cam)
-            hipLaunchKernelGGL((k_eval<true, false>), grid, block, 0, e.stream, a);
-        else
-            hipLaunchKernelGGL((k_eval<false, false>), grid, block, 0, e.stream, a);
-    }
-}
-
-// Both family passes, the per-pose sums and the total cost of this rank's observations.
 // use_ctl: the evaluation of an LM iteration -- at the CANDIDATE poses, blocks into the staging copy of the small
 // buffer (they replace the working copy when the step is accepted), W into the buffer that does not hold W at x.
 // Otherwise (covariance, vmm_ba_eval_blocks, kernel timing): at the current poses, into the working copies.
-void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bool use_ctl)
+void launch_eval_passes(Engine& e, int robustify, double huber_a, bool use_ctl)
 {
-    (void)guard;
     const bool e_is_cam = e.elim_cams;
     const bool lm = use_ctl;
-    EvalArgs aE = make_eval_args(e, e.ordE, e_is_cam, e.f32_accum ? (void*)e.Wf : (void*)e.W, false, lm);
-    EvalArgs aF = make_eval_args(e, e.ordF, !e_is_cam, nullptr, false, lm);
+    EvalArgs aE = make_eval_args(e, e.ordE, e_is_cam, e.f32_accum ? (void*)e.Wf : (void*)e.W, lm);
+    EvalArgs aF = make_eval_args(e, e.ordF, !e_is_cam, nullptr, lm);
     aE.robustify = aF.robustify = robustify;
     aE.huber_a = aF.huber_a = huber_a;
     if (!use_ctl)
@@ -617,7 +540,6 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
             hipLaunchKernelGGL((k_eval_both<false>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
     }
     const LmCtl* ctl = use_ctl ? e.ctl : nullptr;
-    const int gguard = 0;
     // LM loop, world > 1: the staging copy (all-reduced next); one GPU: the copy w_which does not name
     const bool stage = lm && e.multi;
     double* const oH_cam = stage ? e.ev_H_cam : e.H_cam;
@@ -644,16 +566,16 @@ void launch_eval_passes(Engine& e, bool guard, int robustify, double huber_a, bo
     rF.Hout = e_is_cam ? oH_tag : oH_cam;
     rF.gout = e_is_cam ? og_tag : og_cam;
     rF.pose_cost = nullptr;
-    hipLaunchKernelGGL(k_reduce_pose, dim3(((e.n_e + e.n_f) * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, gguard,
-                       rE, rF, (lm && !e.multi) ? e.small_alt_off : (int64_t)0);
+    hipLaunchKernelGGL(k_reduce_pose, dim3(((e.n_e + e.n_f) * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, rE, rF,
+                       (lm && !e.multi) ? e.small_alt_off : (int64_t)0);
     if (e.multi || !use_ctl)   // single-GPU solves sum the pose costs in k_control
-        hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, gguard, e.part_cost, e.n_e, 1,
+        hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, e.part_cost, e.n_e, 1,
                            lm ? e.ev_cost : e.cost_slot);
 }
 
 void launch_sum(Engine& e, bool guard, const double* in, int n, double* out)
 {
-    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, guard ? e.ctl : (const LmCtl*)nullptr, 0, in, n, 1, out);
+    hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, guard ? e.ctl : (const LmCtl*)nullptr, in, n, 1, out);
 }
 
 void launch_cost_kernel(Engine& e, const double* cam, const double* tag, bool guard, int robustify, double huber_a)
@@ -736,22 +658,10 @@ int preload_eval_kernels()
 {
     hipFuncAttributes at;
     int bad = 0;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, true, double>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, true, double>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, false, double>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, false, double>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, true, float>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, true, float>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, false, float>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, false, float>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<true, double>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, double>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<true, float>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, float>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, true, double, true>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, true, double, true>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<true, false, double, true>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval<false, false, double, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<true, double, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, double, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cost<true, true>)) != hipSuccess;

@@ -316,7 +316,6 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
         if (!c.done && moved) {
             const double cst = ccost;
             c.x_cost = cst;
-            c.need_jacobian = 0;
             c.num_jac_evals++;
             if (first) {
                 c.first_eval = 0;

@@ -491,7 +491,7 @@ static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg)
 {
     switch (seg) {
     case 0:
-        launch_eval_passes(e, false, o.robustify, o.huber_a, true);
+        launch_eval_passes(e, o.robustify, o.huber_a, true);
         break;
     case 1:
         launch_control(e);
@@ -701,7 +701,6 @@ static void init_ctl(LmCtl& c, const vmm_ba_options& o, int trace_capacity)
     c.max_lm_diagonal = o.max_lm_diagonal;
     c.radius = o.initial_trust_region_radius;
     c.decrease_factor = 2.0;
-    c.need_jacobian = 1;
     c.first_eval = 1;
     c.termination = VMM_BA_NO_CONVERGENCE;
     c.trace_capacity = trace_capacity;
@@ -1357,7 +1356,7 @@ int vmm_ba_tag_translation_covariance(vmm_ba_handle h, int robustify, double hub
     init_ctl(*e.ctl_host, o, 0);
     HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
     // the iteration's kernels on the undamped, unscaled system: H blocks, Z, S = L L^T (+ block inverses)
-    launch_eval_passes(e, false, robustify, huber_a, false);
+    launch_eval_passes(e, robustify, huber_a, false);
     launch_cov_prepare(e);
     launch_elim(e);
     launch_syrk_reduced(e);
@@ -1469,7 +1468,7 @@ int vmm_ba_eval_blocks(vmm_ba_handle h, int robustify, double huber_a, double* c
         return VMM_BA_ERR_STATE;
     }
     HIP_TRY(hipSetDevice(e.device));
-    launch_eval_passes(e, false, robustify, huber_a, false);
+    launch_eval_passes(e, robustify, huber_a, false);
     HIP_TRY(hipGetLastError());
     if (cost) HIP_TRY(hipMemcpyAsync(cost, e.cost_slot, sizeof(double), hipMemcpyDeviceToHost, e.stream));
     if (V) HIP_TRY(hipMemcpyAsync(V, e.H_cam, sizeof(double) * 36 * e.n_cams, hipMemcpyDeviceToHost, e.stream));
@@ -1711,7 +1710,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     e.ctl_host->done = 0;
     e.ctl_host->lin_fail = 0;
     HIP_TRY(hipMemcpy(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice));
-    if ((rc = timed([&] { launch_eval_passes(e, false, o.robustify, o.huber_a, false); }, nop, &out->eval_elim_ms, 8))) return rc;
+    if ((rc = timed([&] { launch_eval_passes(e, o.robustify, o.huber_a, false); }, nop, &out->eval_elim_ms, 8))) return rc;
     out->eval_keep_ms = 0.0;
     if ((rc = timed([&] { launch_cost_kernel(e, e.cam_qt, e.tag_qt, false, o.robustify, o.huber_a); }, nop, &out->cost_ms, 8))) return rc;
     if ((rc = timed([&] { launch_elim(e); }, nop, &out->form_z_ms, 8))) return rc;

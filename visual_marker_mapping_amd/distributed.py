@@ -3,8 +3,8 @@
 The reference is single-process ("Parallelism strategies: none"); this is the
 MI355X side of BASELINE.json configs[2].  Observations are sharded by the ELIMINATED pose family
 (cameras by default: "observations shard naturally by camera"), every rank keeps all poses, and per
-LM iteration the ranks exchange by sum-all-reduce: the small normal-equation blocks after a Jacobian
-evaluation, the reduced system, the eliminated family's step and the candidate cost.
+LM iteration the ranks exchange by sum-all-reduce: the small normal-equation blocks, gradient and cost of
+the evaluation at the candidate, the reduced system, and the eliminated family's step.
 """
 import numpy as np
 
