@@ -97,7 +97,9 @@ __device__ __forceinline__ void eval_body(const EvalArgs& a, const int wave)
 
     constexpr bool NEED_JC = OWN_IS_CAM || WRITE_W;
     constexpr bool NEED_JT = !OWN_IS_CAM || WRITE_W;
-#pragma unroll
+    // not unrolled: four copies of the corner's temporaries cost 30 more spilled VGPRs (scratch 140 -> 20 B per lane
+    // at two waves per SIMD) and the scratch traffic that goes with them; 31.2 -> 30.0 us for the evaluation
+#pragma unroll 1
     for (int c = 0; c < (POINTS ? 2 : 4); ++c) {
         // LL, LR, UR, UL (include/visual_marker_mapping/TagReconstructor.h:47-50)
         const double sx = (c == 1 || c == 2) ? hw : -hw;
