@@ -117,7 +117,8 @@ def test_observation_mask_equals_a_rebuilt_subproblem(oracle):
         np.testing.assert_allclose(pa[1], pb[1], rtol=1e-9, equal_nan=True)
         np.testing.assert_allclose(pa[2], pb[2], rtol=1e-9)
         assert np.all(pa[0][5:] == -1.0) and np.isnan(pa[1][3])
-        np.testing.assert_allclose(pa[3][keep], pb[3], rtol=1e-9, atol=1e-12)
+        # per-corner errors in pixels (coordinates of a few thousand): the two solves agree to 1e-9 of the pose scale
+        np.testing.assert_allclose(pa[3][keep], pb[3], rtol=1e-9, atol=1e-9)
         assert np.all(pa[3][~keep] == 0.0)
         np.testing.assert_allclose(full.tag_translation_covariance(True), sub.tag_translation_covariance(True),
                                    rtol=1e-6, atol=1e-18)
