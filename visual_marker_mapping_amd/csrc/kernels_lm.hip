@@ -506,12 +506,16 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
         candidate_for_pose(pv, p, d, delta, H, g, active, pose_part);
         return;
     }
-    const int e = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63;
+    // One workgroup per eliminated pose: its four waves split the columns of the pose's six rows of Z (one wave per
+    // pose left half of the SIMDs idle and a ten-deep chain of dependent load rounds: 10.3 us), wave 0 finishes.
+    const int e = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (e >= n_e)
         return;
     const bool owned = pose_task[e + 1] > pose_task[e];
     if (!owned || lin_fail) {
+        if (wave != 0)
+            return;
         if (lane < 6)
             step_comm[6 * (int64_t)e + lane] = 0.0;
         if (lane == 0) {
@@ -523,10 +527,11 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
         }
         return;
     }
+    __shared__ double s_acc[4][6];
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     const double* zr = Z + (int64_t)(6 * e) * ldz;
     // 16-byte loads: n_red = 6 n_f is even and every row of Z starts 16-byte aligned (ldz is even)
-    for (int c = 2 * lane; c < n_red; c += 128) {
+    for (int c = 2 * (int)threadIdx.x; c < n_red; c += 512) {
         const double2 yv = *reinterpret_cast<const double2*>(yf + c);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -534,11 +539,20 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
             acc[i] += zv.x * yv.x + zv.y * yv.y;
         }
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double a = wave_sum(acc[i]);
+        if (lane == 0)
+            s_acc[wave][i] = a;
+    }
+    __syncthreads();
+    if (wave != 0)
+        return;
     double v[6];
     double cr = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const double a = wave_sum(acc[i]);
+        const double a = (s_acc[0][i] + s_acc[1][i]) + (s_acc[2][i] + s_acc[3][i]);
         v[i] = ze[6 * (int64_t)e + i] - a;
         cr += v[i] * a;
     }
@@ -658,7 +672,7 @@ void launch_backsub(Engine& e)
 {
     const int e_off = e.elim_cams ? 0 : e.n_cams;
     const int f_off = e.elim_cams ? e.n_cams : 0;
-    const int nb_e = (e.n_e + 3) / 4;
+    const int nb_e = e.n_e;   // one workgroup per eliminated pose
     if (e.multi) {
         hipLaunchKernelGGL((k_backsub<false>), dim3(nb_e), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
                            e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off,
