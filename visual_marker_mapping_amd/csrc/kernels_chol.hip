@@ -646,11 +646,36 @@ __global__ __launch_bounds__(256) void k_backsolve_step(const LmCtl* ctl, double
 // 8-byte {tag = epoch, 32 value bits} words written by ONE aligned agent-scope (sc1) store each; one wave
 // of the consumer re-reads its 128 granules with sc1 loads until every tag carries this solve's epoch and
 // hands the values to the other waves through LDS.  One L2 round trip per hop instead of two (flag, then
-// payload), no drain + flag store on the producer side.  While it waits, a workgroup already holds the
-// next L tile in registers; the 19 kernel boundaries of the per-block version disappear.
+// payload), no drain + flag store on the producer side; the kernel boundaries of the per-block version disappear.
+//
+// What a hop costs (tools/gpu_chain_stamps.sh): ~0.45 us from a block's publication to its successor seeing it, and
+// -- before this form -- ~0.95 us of work behind it: the product with L(m+1,m)^T, a reduction over the four waves,
+// the product with the inverse of the diagonal block, another reduction (four barriers).  Only ONE product has to
+// wait for y_{m+1}:
+//     y_m = Linv_m^T (w_m - sum_{j>m+1} L(j,m)^T y_j)  -  (L(m+1,m) Linv_m)^T y_{m+1}  =  u_m - B_m^T y_{m+1},
+// u_m is finished one hop earlier and B_m (a 64x64x64 product) while the workgroup waits for the chain to reach it.
+// (Two blocks per workgroup, 10 hops instead of 19, was built first and changed nothing: the work, not the hand-off,
+// was the larger part of a hop.)
 // Every spin is bounded: on a timeout the solve is flagged as failed (treated like a failed Cholesky
 // by the LM loop) and the flag is still published so that no other workgroup is left waiting.
 constexpr unsigned kSpinLimit = 1u << 22;
+
+int backsolve_chain_workgroups(int n_blk) { return n_blk; }
+
+#ifdef VMM_STAMPS
+__device__ unsigned long long g_chain_stamps[128][4];   // [block]: start, last dependency seen, published
+#define CH_RT(blk, slot)                                                                  \
+    do {                                                                                  \
+        if (threadIdx.x == 0)                                                             \
+            g_chain_stamps[(blk) & 127][slot] = __builtin_amdgcn_s_memrealtime();         \
+    } while (0)
+extern "C" int vmm_ba_debug_read_chain_stamps(unsigned long long* out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(unsigned long long) * 128 * 4);
+}
+#else
+#define CH_RT(blk, slot)
+#endif
 
 __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const double* __restrict__ S, int ld,
                                                          int n_pad, int n_blk, double* y,
@@ -665,11 +690,12 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
             *epoch_word = *epoch_word + 1u;
         return;
     }
-    __shared__ double L[64 * kLd];
+    __shared__ double L[64 * kLd];    // L(m+1, m) for the product B_m
+    __shared__ double Li[64 * kLd];   // Linv_m
     __shared__ double red[4][64];
     __shared__ double ws[64];
     __shared__ double ys[2][64];
-    __shared__ double di[64];
+    __shared__ double sB[16][256];    // B_m: [row within a wave's 16][thread that owns the column]
     __shared__ int s_timeout;
     const int m = n_blk - 1 - (int)blockIdx.x;
     const int tid = threadIdx.x;
@@ -678,40 +704,10 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     const int K0 = m * kNB;
     if (tid == 0)
         s_timeout = 0;
-    double li[16];   // my 16 rows of column c of Linv_mm (requested now, used after the last hand-off)
-    if (m < n_blk - 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            li[r] = Linv[(int64_t)m * 4096 + (part * 16 + r) * 64 + c];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            li[r] = 0.0;
-        for (int idx = tid; idx < 64 * 64; idx += 256) {
-            const int r = idx >> 6, cc = idx & 63;
-            L[r * kLd + cc] = (cc <= r) ? Ld[(int64_t)m * 4096 + r * 64 + cc] : 0.0;
-        }
-        if (tid < 64)
-            di[tid] = dinv[K0 + tid];
-    }
-    double acc = 0.0;
-    double lt[16], ln[16];
-    int j = n_blk - 1;
-    if (j > m) {
-        const double* Lb = S + (int64_t)(j * kNB + part * 16) * ld + K0 + c;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            lt[r] = Lb[(int64_t)r * ld];
-    }
-    for (; j > m; --j) {
-        if (j - 1 > m) {   // next tile requested before the wait
-            const double* Lb = S + (int64_t)((j - 1) * kNB + part * 16) * ld + K0 + c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ln[r] = Lb[(int64_t)r * ld];
-        }
-        double* ysj = ys[j & 1];
-        if (part == 0) {   // wave 0 sweeps block j's granules: lane c owns unknown c (two granules)
+    CH_RT(m, 0);
+    // wave 0 sweeps block j's granules into ysj: lane c owns unknown c (two granules)
+    auto receive = [&](const int j, double* ysj) {
+        if (part == 0) {
             const unsigned long long* g = gran + 2 * (int64_t)(j * kNB + c);
             unsigned long long x0, x1;
             for (unsigned n = 0;;) {
@@ -728,6 +724,99 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
             }
             ysj[c] = __longlong_as_double((long long)(((x1 & 0xffffffffull) << 32) | (x0 & 0xffffffffull)));
         }
+    };
+    auto publish = [&](const double yv) {   // wave 0
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(yv);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        unsigned long long* g = gran + 2 * (int64_t)(K0 + c);
+        __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[K0 + c] = yv;   // for the kernels after this launch
+    };
+    if (m == n_blk - 1) {
+        // The last block is the first in the chain and has no inverse (nothing runs beside its factorisation).  ONE
+        // wave solves L^T y = w by columns, lane c holding w[c]: 64 steps of (broadcast y_j from lane j, one
+        // multiply-add per lane) on registers only -- no barrier, no LDS in the dependent chain.
+        if (part == 0) {
+            double lcol[64];
+#pragma unroll
+            for (int jj = 0; jj < 64; ++jj)
+                lcol[jj] = (c <= jj) ? Ld[(int64_t)m * 4096 + jj * 64 + c] : 0.0;
+            const double dic = dinv[K0 + c];
+            double wv = S[(int64_t)n_pad * ld + K0 + c];
+            double yv = 0.0;
+#pragma unroll
+            for (int jj = 63; jj >= 0; --jj) {
+                // v_readlane (jj is a constant), not a cross-lane permute through the LDS
+                const long long wb = __double_as_longlong(wv * dic);
+                const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)wb, jj);
+                const unsigned w1 = (unsigned)__builtin_amdgcn_readlane((int)(wb >> 32), jj);
+                const double yj = __longlong_as_double((long long)(((unsigned long long)w1 << 32) | w0));
+                yv = (c == jj) ? yj : yv;
+                wv = (c < jj) ? wv - lcol[jj] * yj : wv;
+            }
+            publish(yv);
+        }
+        CH_RT(m, 2);
+        if (tid == 0 && m == 0)
+            *epoch_word = epoch;   // a single block: also the end of the chain
+        return;   // no wait, so no timeout
+    }
+    // ---- B_m = L(m+1, m) Linv_m on the matrix cores: wave `part` computes rows part*16 .. part*16+15 ----
+    // (as 16 x 64 dot products per thread with broadcast LDS reads it took 15 us: every workgroup was late for its hop)
+    double li[16];
+    {
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int r = idx >> 6, cc = idx & 63;
+            L[r * kLd + cc] = S[(int64_t)((m + 1) * kNB + r) * ld + K0 + cc];
+            Li[r * kLd + cc] = Linv[(int64_t)m * 4096 + r * 64 + cc];   // lower triangular, zero above the diagonal
+        }
+        __syncthreads();
+        // li: my 16 rows of column c of Linv_m, for u_m = Linv_m^T t
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            li[r] = Li[(part * 16 + r) * kLd + c];
+        // v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+        // C[row = (lane >> 4) + 4 reg][col = lane & 15]
+        const int fi = c & 15, fk = c >> 4;
+        double4_t accB[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            accB[t] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double av = L[(part * 16 + fi) * kLd + 4 * ks + fk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                accB[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Li[(4 * ks + fk) * kLd + 16 * t + fi], accB[t], 0, 0, 0);
+        }
+        // to the layout the hop reads: sB[row within my 16][workgroup thread that owns the column]
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sB[fk + 4 * r][part * 64 + 16 * t + fi] = accB[t][r];
+        __syncthreads();
+    }
+    // ---- the blocks behind m+1: acc = sum_j L(j, m)^T y_j ----
+    double acc = 0.0;
+    double lt[16], ln[16];
+    int j = n_blk - 1;
+    if (j > m + 1) {
+        const double* Lb = S + (int64_t)(j * kNB + part * 16) * ld + K0 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            lt[r] = Lb[(int64_t)r * ld];
+    }
+    for (; j > m + 1; --j) {
+        if (j - 1 > m + 1) {   // next tile requested before the wait
+            const double* Lb = S + (int64_t)((j - 1) * kNB + part * 16) * ld + K0 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ln[r] = Lb[(int64_t)r * ld];
+        }
+        double* ysj = ys[j & 1];
+        receive(j, ysj);
         __syncthreads();   // also orders the reuse of ys[j & 1] two hops later
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -736,60 +825,41 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
         for (int r = 0; r < 16; ++r)
             lt[r] = ln[r];
     }
+    // ---- u_m = Linv_m^T (w_m - acc): one hop ahead of the value it will be combined with ----
     red[part][c] = acc;
     __syncthreads();
-    double wc = 0.0;
     if (part == 0)
-        wc = S[(int64_t)n_pad * ld + K0 + c] - ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
-    double yv = 0.0;
-    if (m < n_blk - 1) {
-        // y_m = Linv^T t : the inverse of this block was computed beside a later panel; 64x64 GEMV
-        if (part == 0)
-            ws[c] = wc;
-        __syncthreads();
-        double a2 = 0.0;
+        ws[c] = S[(int64_t)n_pad * ld + K0 + c] - ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    __syncthreads();
+    double a2 = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            a2 += li[r] * ws[part * 16 + r];
-        __syncthreads();   // everyone has read red[] above and ws
-        red[part][c] = a2;
-        __syncthreads();
-        if (part == 0)
-            yv = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    } else {
-        // last block (first in the chain): its inverse is not available, solve four unknowns per round
-        for (int j0 = 60; j0 >= 0; j0 -= 4) {
-            if (part == 0)
-                ws[c] = wc;
-            __syncthreads();
-            if (part == 0) {
-                const double* D = L + j0 * kLd + j0;
-                const double v3 = ws[j0 + 3] * di[j0 + 3];
-                const double v2 = (ws[j0 + 2] - D[3 * kLd + 2] * v3) * di[j0 + 2];
-                const double v1 = (ws[j0 + 1] - D[2 * kLd + 1] * v2 - D[3 * kLd + 1] * v3) * di[j0 + 1];
-                const double v0 = (ws[j0] - D[kLd] * v1 - D[2 * kLd] * v2 - D[3 * kLd] * v3) * di[j0];
-                if (c >= j0 && c < j0 + 4)
-                    yv = (c == j0) ? v0 : (c == j0 + 1 ? v1 : (c == j0 + 2 ? v2 : v3));
-                if (c < j0)
-                    wc -= L[j0 * kLd + c] * v0 + L[(j0 + 1) * kLd + c] * v1 + L[(j0 + 2) * kLd + c] * v2
-                        + L[(j0 + 3) * kLd + c] * v3;
-            }
-            __syncthreads();
-        }
-    }
-    if (part == 0) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(yv);
-        const unsigned long long tag = (unsigned long long)epoch << 32;
-        unsigned long long* g = gran + 2 * (int64_t)(K0 + c);
-        __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        y[K0 + c] = yv;   // for the kernels after this launch
-        if (tid == 0) {
-            if (s_timeout)
-                ctl->lin_fail = 1;
-            if (m == 0)
-                *epoch_word = epoch;   // block 0 is the end of the chain: every other workgroup has read the old value
-        }
+    for (int r = 0; r < 16; ++r)
+        a2 += li[r] * ws[part * 16 + r];
+    __syncthreads();   // everyone has read red[] above
+    red[part][c] = a2;
+    __syncthreads();
+    double u = 0.0;
+    if (part == 0)
+        u = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    // ---- the hop: y_m = u_m - B_m^T y_{m+1} ----
+    double* ysj = ys[(m + 1) & 1];
+    receive(m + 1, ysj);
+    __syncthreads();   // also: everyone has read red[] above
+    CH_RT(m, 1);
+    double a3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        a3 += sB[r][tid] * ysj[part * 16 + r];
+    red[part][c] = a3;
+    __syncthreads();
+    if (part == 0)
+        publish(u - ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])));
+    CH_RT(m, 2);
+    if (tid == 0) {
+        if (s_timeout)
+            ctl->lin_fail = 1;
+        if (m == 0)
+            *epoch_word = epoch;   // block 0 is the end of the chain: every other workgroup has read the old value
     }
 }
 
@@ -1571,7 +1641,7 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         a.epoch_word = e.flags + 256;
         a.abort_word = e.flags + 257;
         hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(n_blk)), dim3(256), 0, e.stream, a);
-        hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
+        hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
                            e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
         return;
     }
@@ -1596,7 +1666,7 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
     // one chained launch while every workgroup of the chain is certainly resident (one per CU); the per-block
     // kernels otherwise
     if (chain) {
-        hipLaunchKernelGGL(k_backsolve_chain, dim3(n_blk), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
+        hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
                            e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
     } else {
         for (int kb = n_blk - 1; kb >= 0; --kb)
