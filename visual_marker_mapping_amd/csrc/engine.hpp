@@ -189,6 +189,8 @@ struct Engine {
     int graph_robustify = -1;
     double graph_huber_a = 0.0;
     bool use_graph = true;
+    int graph_passes = 2;           // LM passes recorded into one iteration graph (VMM_BA_GRAPH_PASSES; 2 measured best)
+    int last_passes = 1;            // passes the last run_iteration enqueued
     bool eager_first = false;       // VMM_BA_EAGER_FIRST=1: the handle's first iteration is enqueued without capture
     bool launched_eagerly = false;
 

@@ -612,6 +612,7 @@ static const char* const kSegName[kNumSeg] = { "evaluation at the candidate", "d
 // error during capture" at 2000 x 1000; VMM_BA_EAGER_FIRST=1 brings that back.
 static int run_iteration(Engine& e, const vmm_ba_options& o)
 {
+    e.last_passes = 1;
     if (!e.use_graph)
         return enqueue_iteration(e, o);
     if (e.eager_first && !e.launched_eagerly) {
@@ -624,15 +625,18 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
         drop_graphs(e);
         int rc;
         if (one_graph) {
+            // graph_passes passes in one graph: nothing separates two passes inside a graph (~9 us between two graph
+            // launches); the passes behind the terminating one find `done` set and return at once
             rc = capture_graph(e, &e.iter_graph, [&](const char** where) -> int {
-                for (int seg = 0; seg < kNumSeg; ++seg) {
-                    enqueue_segment(e, o, seg);
-                    int r;
-                    if (e.multi && (r = allreduce_after(e, seg)))
-                        return r;
-                    if (capture_alive(e))
-                        *where = kSegName[seg];
-                }
+                for (int pass = 0; pass < e.graph_passes; ++pass)
+                    for (int seg = 0; seg < kNumSeg; ++seg) {
+                        enqueue_segment(e, o, seg);
+                        int r;
+                        if (e.multi && (r = allreduce_after(e, seg)))
+                            return r;
+                        if (capture_alive(e))
+                            *where = kSegName[seg];
+                    }
                 return VMM_BA_OK;
             });
             if (rc && e.multi && e.rccl_comm) {
@@ -660,6 +664,7 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
     Range r("vmm_ba lm_iteration");
     if (one_graph) {
         HIP_TRY(hipGraphLaunch(e.iter_graph, e.stream));
+        e.last_passes = e.graph_passes;
         return VMM_BA_OK;
     }
     int rc;
@@ -879,6 +884,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         e.rccl_graph = !(rg && rg[0] == '0');
         const char* ng = getenv("VMM_BA_NO_GRAPH");
         e.use_graph = !(ng && ng[0] == '1');
+        if (const char* gp = getenv("VMM_BA_GRAPH_PASSES"))
+            e.graph_passes = std::min(std::max(atoi(gp), 1), 8);
         const char* nc = getenv("VMM_BA_NO_CHAIN");
         e.no_chain = nc && nc[0] == '1';
         const char* nd = getenv("VMM_BA_NO_DATAFLOW");
@@ -1208,8 +1215,10 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
     int64_t enq = 0;
     for (;;) {
         int rc;
-        for (int k = 0; k < poll && enq < max_steps; ++k, ++enq)
+        for (int k = 0; k < poll && enq < max_steps; ++k) {
             if ((rc = run_iteration(e, o))) return rc;
+            enq += e.last_passes;
+        }
         HIP_TRY(hipMemcpyAsync(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream));
         HIP_TRY(hipStreamSynchronize(e.stream));
         if (e.ctl_host->done)
@@ -1732,13 +1741,16 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     if ((rc = vmm_ba_set_state(h, cam0.data(), tag0.data()))) return rc;
     if ((rc = begin_lm_loop(e, ot, 0))) return rc;
     HIP_TRY(hipEventRecord(ev0, e.stream));
-    for (int r = 0; r < reps; ++r)
+    int passes = 0;
+    for (int r = 0; r < reps; ++r) {
         if ((rc = run_iteration(e, ot))) return rc;
+        passes += e.last_passes;
+    }
     HIP_TRY(hipEventRecord(ev1, e.stream));
     HIP_TRY(hipEventSynchronize(ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    out->lm_iteration_ms = ms / reps;
+    out->lm_iteration_ms = ms / passes;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     return vmm_ba_set_state(h, cam0.data(), tag0.data());
