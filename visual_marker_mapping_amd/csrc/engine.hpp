@@ -180,6 +180,10 @@ struct Engine {
 
     LmCtl* ctl = nullptr;           // device
     LmCtl* ctl_host = nullptr;      // pinned
+    // vmm_ba_set_state: the caller's poses are staged here (pinned) and copied on the stream without waiting for it
+    double* pose_stage = nullptr;   // [7 * (n_cams + n_tags)]
+    hipEvent_t pose_ev = nullptr;   // recorded behind the copies: the staging buffer is free again
+    bool pose_ev_pending = false;
     vmm_ba_iteration* trace = nullptr;  // device
     int trace_capacity = 0;
 

@@ -473,6 +473,10 @@ static void destroy_engine(Engine* e)
         (void)hipFree(p);
     if (e->ctl_host)
         (void)hipHostFree(e->ctl_host);
+    if (e->pose_stage)
+        (void)hipHostFree(e->pose_stage);
+    if (e->pose_ev)
+        (void)hipEventDestroy(e->pose_ev);
     if (e->stream)
         (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1019,6 +1023,11 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         return fail(VMM_BA_ERR_HIP);
     }
     memset(e.ctl_host, 0, sizeof(LmCtl));
+    if (hipHostMalloc((void**)&e.pose_stage, sizeof(double) * 7 * (size_t)n_pose) != hipSuccess
+        || hipEventCreateWithFlags(&e.pose_ev, hipEventDisableTiming) != hipSuccess) {
+        set_error("hipHostMalloc / hipEventCreate (pose staging) failed");
+        return fail(VMM_BA_ERR_HIP);
+    }
     e.trace_capacity = 0;
     if (hipStreamSynchronize(e.stream) != hipSuccess) {
         set_error("create: device synchronisation failed");
@@ -1104,16 +1113,31 @@ int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt
     }
     Engine& e = *reinterpret_cast<Engine*>(h);
     HIP_TRY(hipSetDevice(e.device));
-    if (cam_qt)
-        HIP_TRY(hipMemcpyAsync(e.cam_qt, cam_qt, sizeof(double) * 7 * e.n_cams, hipMemcpyHostToDevice, e.stream));
     std::vector<double> pairs;
     if (tag_qt && e.points) {   // tag poses -> their corners, as at create
         pairs = pairs_from_tags(tag_qt, e.user_tag_wh.data(), e.n_tags_user);
         tag_qt = pairs.data();
     }
-    if (tag_qt)
-        HIP_TRY(hipMemcpyAsync(e.tag_qt, tag_qt, sizeof(double) * 7 * e.n_tags, hipMemcpyHostToDevice, e.stream));
-    HIP_TRY(hipStreamSynchronize(e.stream));
+    // Staged through pinned memory and copied on the stream: the call does not wait for the device (everything that
+    // uses the poses afterwards is ordered behind the copies on the same stream); ~8 us instead of ~30 per call.
+    if (e.pose_ev_pending) {
+        HIP_TRY(hipEventSynchronize(e.pose_ev));   // the previous call's copies have left the staging buffer
+        e.pose_ev_pending = false;
+    }
+    double* stage_cam = e.pose_stage;
+    double* stage_tag = e.pose_stage + (size_t)7 * e.n_cams;
+    if (cam_qt) {
+        memcpy(stage_cam, cam_qt, sizeof(double) * 7 * e.n_cams);
+        HIP_TRY(hipMemcpyAsync(e.cam_qt, stage_cam, sizeof(double) * 7 * e.n_cams, hipMemcpyHostToDevice, e.stream));
+    }
+    if (tag_qt) {
+        memcpy(stage_tag, tag_qt, sizeof(double) * 7 * e.n_tags);
+        HIP_TRY(hipMemcpyAsync(e.tag_qt, stage_tag, sizeof(double) * 7 * e.n_tags, hipMemcpyHostToDevice, e.stream));
+    }
+    if (cam_qt || tag_qt) {
+        HIP_TRY(hipEventRecord(e.pose_ev, e.stream));
+        e.pose_ev_pending = true;
+    }
     return VMM_BA_OK;
 }
 
