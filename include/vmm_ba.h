@@ -198,8 +198,9 @@ void vmm_ba_destroy(vmm_ba_handle h);
 
 /* Poses live on the device between calls (the reference mutates map nodes in place through raw
  * double*, src/TagReconstructor.cpp:665-666,692-693,722).  vmm_ba_set_state copies the caller's arrays into
- * pinned staging memory and returns without waiting for the device: the caller's buffers are free at once, every
- * later call on the handle is ordered behind the upload.  Either pointer may be NULL (that family is left alone). */
+ * pinned staging memory and issues no device command: the caller's buffers are free at once, and the next call that
+ * needs the poses on the device uploads them (vmm_ba_solve inside the one launch that starts its loop).  Either
+ * pointer may be NULL (that family is left alone). */
 int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt);
 int vmm_ba_get_state(vmm_ba_handle h, double* cam_qt, double* tag_qt);
 

@@ -184,6 +184,8 @@ struct Engine {
     double* pose_stage = nullptr;   // [7 * (n_cams + n_tags)]
     hipEvent_t pose_ev = nullptr;   // recorded behind the copies: the staging buffer is free again
     bool pose_ev_pending = false;
+    double* pose_stage_dev = nullptr;   // the staging buffer as the device sees it (k_begin_loop reads it directly)
+    bool dirty_cam = false, dirty_tag = false;   // staged by vmm_ba_set_state, not yet on the device
     vmm_ba_iteration* trace = nullptr;  // device
     int trace_capacity = 0;
 
@@ -238,6 +240,7 @@ void launch_cov_trsm(Engine& e, double* B, int ldb, int n_chunks, bool identity_
 void launch_cov_gram(Engine& e, const double* X, int ldb, double* cov_dev);
 // kernels_lm.hip
 void launch_control(Engine& e);
+void launch_begin_loop(Engine& e, const LmCtl& init);
 void launch_pose_plus(hipStream_t st, int64_t n, const double* qt, const double* delta, double* out);
 void launch_backsub(Engine& e);
 void launch_candidate(Engine& e);

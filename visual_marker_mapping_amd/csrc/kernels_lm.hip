@@ -609,6 +609,49 @@ __global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_p
     candidate_for_pose(pv, p, d, delta, H, g, active, pose_part);
 }
 
+// Start of an LM loop in ONE launch: the control block (passed by value), the poses vmm_ba_set_state staged in pinned
+// host memory (read over the bus: 39 KB at 500 x 200) into the state, and the state into the candidate buffers -- five
+// stream-ordered copies of a few microseconds each before.
+__global__ __launch_bounds__(256) void k_begin_loop(LmCtl* ctl, const LmCtl init, const int n_cam7, const int n_tag7,
+                                                    const double* __restrict__ stage_cam,
+                                                    const double* __restrict__ stage_tag, double* __restrict__ cam_qt,
+                                                    double* __restrict__ tag_qt, double* __restrict__ cam_cand,
+                                                    double* __restrict__ tag_cand)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0)
+        *ctl = init;
+    if (i < n_cam7) {
+        double v;
+        if (stage_cam) {
+            v = stage_cam[i];
+            cam_qt[i] = v;
+        } else {
+            v = cam_qt[i];
+        }
+        cam_cand[i] = v;
+    } else if (i < n_cam7 + n_tag7) {
+        const int k = i - n_cam7;
+        double v;
+        if (stage_tag) {
+            v = stage_tag[k];
+            tag_qt[k] = v;
+        } else {
+            v = tag_qt[k];
+        }
+        tag_cand[k] = v;
+    }
+}
+
+void launch_begin_loop(Engine& e, const LmCtl& init)
+{
+    const int n_cam7 = 7 * e.n_cams, n_tag7 = 7 * e.n_tags;
+    const double* sc = e.dirty_cam ? e.pose_stage_dev : nullptr;
+    const double* st = e.dirty_tag ? e.pose_stage_dev + n_cam7 : nullptr;
+    hipLaunchKernelGGL(k_begin_loop, dim3((n_cam7 + n_tag7 + 255) / 256), dim3(256), 0, e.stream, e.ctl, init, n_cam7,
+                       n_tag7, sc, st, e.cam_qt, e.tag_qt, e.cam_cand, e.tag_cand);
+}
+
 // Diagnostic (vmm_ba_pose_plus): the Plus the LM loop applies, on caller-supplied poses and tangent steps.
 __global__ void k_pose_plus(int64_t n, const double* __restrict__ qt, const double* __restrict__ delta,
                             double* __restrict__ out)
@@ -703,6 +746,7 @@ int preload_lm_kernels()
     hipFuncAttributes at;
     int bad = 0;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_control)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_begin_loop)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<false>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_candidate)) != hipSuccess;
