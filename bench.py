@@ -109,9 +109,30 @@ def main():
                             world_size=world,
                             precision=eng.PRECISION_F32_ACCUM if precision == "f32" else eng.PRECISION_F64)
     setup_s = time.time() - t0
+    collective_used = None
     if use_dist:
+        collective_used = a.collective
         if a.collective == "rccl":
-            vdist.enable_native_rccl(ba, rank)             # ncclAllReduce inside the iteration's hipGraph
+            # ncclAllReduce inside the iteration's hipGraph.  If the library's own communicator cannot be set up on
+            # some rank (librccl.so not loadable, ncclCommInitRank error), ALL ranks fall back to the host-callback
+            # path together -- the decision is all-reduced so that nobody is left in a collective alone.
+            err = None
+            try:
+                vdist.enable_native_rccl(ba, rank)
+            except Exception as exc:   # noqa: BLE001 -- reported in the JSON line
+                err = exc
+            bad = torch.tensor([1.0 if err is not None else 0.0], device="cuda")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if float(bad.item()) > 0.0:
+                if err is None:
+                    # this rank has a communicator the others do not: start over on the callback path
+                    ba.close()
+                    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag,
+                                            s.obs_cam[idx], s.obs_tag[idx], s.obs_px[idx], device=local_rank,
+                                            elimination=elim, rank=rank, world_size=world,
+                                            precision=eng.PRECISION_F32_ACCUM if precision == "f32" else eng.PRECISION_F64)
+                ba.set_allreduce(vdist.make_allreduce(local_rank))
+                collective_used = "callback (native RCCL set-up failed%s)" % (": %s" % err if err is not None else " on another rank")
         else:
             ba.set_allreduce(vdist.make_allreduce(local_rank))   # host callback -> torch.distributed
     robust = 1 if s.robustify else 0
@@ -158,6 +179,8 @@ def main():
             "residual_evals_per_sec": res_evals_per_s,
             "setup_s": setup_s,
         }
+        if collective_used is not None:
+            line["collective"] = collective_used
     if world == 1 and not use_dist:
         ba.set_state(s.cam_init, s.tag_init)
         kt = ba.time_kernels(eng.default_options(**opts_kw), reps=10)

@@ -86,6 +86,13 @@ def enable_native_rccl(ba, rank, group=None):
     import torch.distributed as dist
     from . import engine as eng
 
-    payload = [eng.rccl_unique_id() if rank == 0 else None]
+    payload = [None]
+    if rank == 0:
+        try:
+            payload[0] = eng.rccl_unique_id()
+        except Exception as exc:   # noqa: BLE001 -- carried to every rank so that all of them raise together
+            payload[0] = "rank 0 could not draw an RCCL id: %s" % exc
     dist.broadcast_object_list(payload, src=0, group=group)
+    if not isinstance(payload[0], (bytes, bytearray)):
+        raise RuntimeError(str(payload[0]))
     ba.enable_rccl(payload[0])
