@@ -239,6 +239,13 @@ def main():
         if dom == "cholesky_solve":
             line["roofline"]["launches"] = ({"k_chol_dataflow": 1, "k_backsolve_chain": 1} if dataflow
                                             else {"k_chol_step": n_blk, "k_backsolve_chain": 1})
+            if dataflow:
+                # informational: what actually bounds this group (measured with the stamps build) --
+                # 8 rounds of 8 dependent pivots per block column at ~1.0 us, one granule hand-off (~1.3 us) between
+                # block columns, then n_blk hops of ~1.1 us in the back-substitution
+                floor_ms = 1e-3 * (8 * n_blk * 1.0 + (n_blk - 1) * 1.3 + 4.4 + (n_blk - 1) * 1.1)
+                line["roofline"]["latency_model"] = {"floor_ms": floor_ms, "frac_of_floor": floor_ms / d["ms"],
+                                                     "source": "DESIGN.md sections 4.1 and 4.4 (in-kernel time stamps)"}
             line["roofline"]["note"] = ("avg_launch_ms, achieved and traffic are for one whole factorisation + solve (the "
                                         "launches above, back to back); algorithmic flops n^3/3 + 2 n^2; bound by the %d "
                                         "dependent pivots (a chain of 8-column rounds at ~1 us each), not by the matrix "
