@@ -328,3 +328,42 @@ def test_random_scenes_match_oracle(oracle):
         assert ok_gpu == ok_ref, msg
         np.testing.assert_allclose(out["final_cost"], summ["final_cost"], rtol=1e-7, err_msg=msg)
     assert n_rejecting >= 2
+
+
+def test_passes_per_graph_do_not_change_the_solve(monkeypatch):
+    """The iteration graph holds VMM_BA_GRAPH_PASSES LM passes (default 2); passes recorded behind the terminating one
+    find `done` set and return at once.  One, two, three passes per graph and eager launches (VMM_BA_NO_GRAPH=1) run
+    the same kernels in the same order: the solves must be bit-identical, also when the pass count of the solve is
+    not a multiple of the passes per graph (max_num_iterations = 4)."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1)
+    res = []
+    for env in ({"VMM_BA_GRAPH_PASSES": "1"}, {"VMM_BA_GRAPH_PASSES": "2"}, {"VMM_BA_GRAPH_PASSES": "3"},
+                {"VMM_BA_NO_GRAPH": "1"}):
+        for k in ("VMM_BA_GRAPH_PASSES", "VMM_BA_NO_GRAPH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                                s.obs_px)
+        try:
+            full = ba.solve(eng.default_options(robustify=1), trace_capacity=64)
+            state = ba.get_state()
+            ba.set_state(s.cam_init, s.tag_init)
+            capped = ba.solve(eng.default_options(robustify=1, max_num_iterations=4), trace_capacity=64)
+            state4 = ba.get_state()
+        finally:
+            ba.close()
+        res.append((full, state, capped, state4))
+    ref = res[0]
+    assert ref[2]["termination_type"] == eng.NO_CONVERGENCE and ref[2]["iterations"] == 5
+    for full, state, capped, state4 in res[1:]:
+        for a, b in ((full, ref[0]), (capped, ref[2])):
+            assert a["iterations"] == b["iterations"] and a["termination_type"] == b["termination_type"]
+            assert a["final_cost"] == b["final_cost"]
+            assert [t["cost"] for t in a["trace"]] == [t["cost"] for t in b["trace"]]
+        np.testing.assert_array_equal(state[0], ref[1][0])
+        np.testing.assert_array_equal(state[1], ref[1][1])
+        np.testing.assert_array_equal(state4[0], ref[3][0])
+        np.testing.assert_array_equal(state4[1], ref[3][1])
