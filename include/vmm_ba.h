@@ -119,8 +119,8 @@ typedef struct vmm_ba_options {
     int32_t max_num_consecutive_invalid_steps; /* 5 */
     int32_t jacobi_scaling;            /* 1 */
     int32_t num_threads;               /* accepted for signature parity (:733); the GPU path ignores it */
-    int32_t poll_interval;             /* LM iterations enqueued between host polls of the device
-                                          control block (>=1); does not change results */
+    int32_t poll_interval;             /* iteration-graph launches (two LM passes each) enqueued between host
+                                          polls of the device control block (>=1); does not change results */
 } vmm_ba_options;
 
 /* One row of Ceres' Solver::Summary::iterations. */
