@@ -261,20 +261,27 @@ def main():
                                                                     "time_step_s", "time_control_s", "time_solve_s")}
         if not a.no_cpu_baseline:
             from oracle import oracle as O
-            threads = min(os.cpu_count() or 1, 64)
-            sc = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
-                         s.obs_px)
-            # untimed: one LM iteration on a copy starts the OpenMP team and touches the work arrays (the first
-            # parallel region of a process costs ~0.5 s on a 64-thread host, half of a 7-iteration solve)
-            scw = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
-                          s.obs_px)
-            O.solve(scw, O.default_options(robustify=robust, num_threads=threads, max_num_iterations=1,
-                                           linear_solver=O.SCHUR_AUTO))
-            t0 = time.perf_counter()
-            summ, _ = O.solve(sc, O.default_options(robustify=robust, num_threads=threads,
-                                                    linear_solver=O.SCHUR_AUTO))
-            dt = time.perf_counter() - t0
-            cpu_iters = summ["num_cost_evals"]   # one cost evaluation per LM iteration
+            # Thread counts tried: every visible core (capped at 64) and the CPU share of a one-GPU box (16: with a
+            # quota smaller than the visible core count, 64 threads oversubscribe and run at half the speed); the
+            # faster one is reported, `cores` = its thread count.
+            n_vis = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
+            best = None
+            for threads in sorted({n_vis, min(n_vis, 16)}, reverse=True):
+                # untimed: one LM iteration on a copy starts the OpenMP team and touches the work arrays (the first
+                # parallel region of a process costs ~0.5 s on a 64-thread host, half of a 7-iteration solve)
+                scw = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                              s.obs_px)
+                O.solve(scw, O.default_options(robustify=robust, num_threads=threads, max_num_iterations=1,
+                                               linear_solver=O.SCHUR_AUTO))
+                sc = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                             s.obs_px)
+                t0 = time.perf_counter()
+                summ, _ = O.solve(sc, O.default_options(robustify=robust, num_threads=threads,
+                                                        linear_solver=O.SCHUR_AUTO))
+                dt_t = time.perf_counter() - t0
+                if best is None or summ["num_cost_evals"] / dt_t > best[0]:
+                    best = (summ["num_cost_evals"] / dt_t, threads, summ["num_cost_evals"], dt_t)
+            _, threads, cpu_iters, dt = best   # one cost evaluation per LM iteration
             # the same oracle on ONE thread, bounded to two LM iterations (single-threaded and
             # all-cores timings)
             sc1 = O.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
