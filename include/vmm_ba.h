@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VMM_BA_ABI_VERSION 2
+#define VMM_BA_ABI_VERSION 3
 
 typedef struct vmm_ba_handle_s* vmm_ba_handle;
 
@@ -161,6 +161,18 @@ typedef struct vmm_ba_summary {
     double time_factor_solve_s;     /* dense Cholesky + triangular solves (Ceres: "Linear solver") */
     double time_step_s;             /* back-substitution, candidate, cost at the candidate */
     double time_control_s;          /* trust-region control kernels */
+    /* The one-launch factorisation (k_chol_dataflow) and back-substitution (k_backsolve_chain) hand data between
+     * workgroups with bounded spins.  A spin that gives up (a GPU time-sliced between processes, a profiler
+     * serialising workgroups) is NOT a numerical failure and never reaches the trust-region policy: the library
+     * redoes that pass's factorisation on the launch-per-block-column path and goes on, so the trajectory is the
+     * one of an undisturbed run.  These two fields report that it happened. */
+    int32_t num_sync_timeouts;      /* LM passes of this solve whose factorisation was redone on the fallback path */
+    int32_t sync_timeout_kernels;   /* OR over those passes: 1 = k_chol_dataflow, 2 = k_backsolve_chain gave up,
+                                       4 = another rank reported a give-up (world_size > 1) */
+    int32_t block_sparse;           /* 1: the elimination ran over co-observed (camera, tag) pairs only (compressed Z,
+                                       k_schur_rows) -- what the handle chose at create from its block structure,
+                                       VMM_BA_SCHUR=dense|sparse overrides; 0: dense Z + MFMA rank-k update */
+    int32_t reserved2;
 } vmm_ba_summary;
 
 /* Sum-all-reduce of `count` doubles in DEVICE memory, in place, ordered on `hip_stream`
@@ -176,13 +188,17 @@ typedef struct vmm_ba_kernel_times {
     double eval_keep_ms;     /* 0 since the two passes share a launch (kept for layout compatibility) */
     double cost_ms;          /* cost-only residual pass */
     double form_z_ms;        /* block factor + Z = L^-1 W */
-    double syrk_ms;          /* reduced system: S -= Z^T Z (f64 MFMA) */
+    double syrk_ms;          /* reduced system: S -= Z^T Z (dense: f64 MFMA rank-k update; block-sparse: k_schur_rows) */
     double cholesky_ms;      /* dense Cholesky + triangular solves of the reduced system */
     double backsub_ms;       /* back-substitution + Plus + model cost */
     double lm_iteration_ms;  /* one whole LM iteration as enqueued by vmm_ba_solve */
     int64_t n_obs;
     int32_t reduced_dim;     /* order of the dense reduced system (without padding) */
     int32_t elim_dim;        /* 6 * number of eliminated poses */
+    int32_t schur_sparse;    /* 1: the reduced system is formed over co-observed (e, f) pairs only (compressed Z) */
+    int32_t reserved;
+    double schur_flops;      /* algorithmic flops of that formation: dense (n+1)(n+2) K; block-sparse 432 per pair of
+                                observations sharing an eliminated pose (lower triangle) + the right-hand side */
 } vmm_ba_kernel_times;
 
 const char* vmm_ba_last_error(void);
@@ -200,7 +216,11 @@ void vmm_ba_destroy(vmm_ba_handle h);
  * double*, src/TagReconstructor.cpp:665-666,692-693,722).  vmm_ba_set_state copies the caller's arrays into
  * pinned staging memory and issues no device command: the caller's buffers are free at once, and the next call that
  * needs the poses on the device uploads them (vmm_ba_solve inside the one launch that starts its loop).  Either
- * pointer may be NULL (that family is left alone). */
+ * pointer may be NULL (that family is left alone).
+ * VMM_BA_LANDMARK_POINTS handles: get_state followed by set_state is NOT the identity on the tag family --
+ * get_state returns poses rebuilt (and re-orthogonalised) from the optimised corners, set_state regenerates exact
+ * rectangles from pose and tag_wh, as vmm_ba_create does (src/TagReconstructor.cpp:483-491 / :608-639); the free
+ * corners themselves are read with vmm_ba_get_points. */
 int vmm_ba_set_state(vmm_ba_handle h, const double* cam_qt, const double* tag_qt);
 int vmm_ba_get_state(vmm_ba_handle h, double* cam_qt, double* tag_qt);
 
@@ -217,6 +237,10 @@ int vmm_ba_set_allreduce(vmm_ba_handle h, vmm_ba_allreduce_fn fn, void* user);
  * has (MPI, torch.distributed, a file), and every rank calls vmm_ba_enable_rccl -- a collective call; rank and
  * world size are those of vmm_ba_create_options.  Takes precedence over a vmm_ba_set_allreduce callback. */
 #define VMM_BA_RCCL_ID_BYTES 128
+/* 1 when librccl.so and every entry point the library uses were resolved in this process, else 0 (no device call).
+ * Launchers ask every rank for this and agree on the answer BEFORE any rank enters vmm_ba_enable_rccl: a rank that
+ * cannot load RCCL would otherwise leave the others blocked inside ncclCommInitRank. */
+int vmm_ba_rccl_available(void);
 int vmm_ba_rccl_unique_id(void* id128);
 int vmm_ba_enable_rccl(vmm_ba_handle h, const void* id128);
 

@@ -111,6 +111,25 @@ inline void printFullReport(const vmm_ba_summary& s)
               << ", host / idle " << (s.time_solve_s > accounted ? s.time_solve_s - accounted : 0.0) << std::endl;
 }
 
+// The covariance report of the final bundle adjustment (src/TagReconstructor.cpp:761-782): per-tag standard deviations
+// of the translation and the "Marker Position RMS" line.  cov = 9 doubles per entry of tag_ids (row-major 3x3).
+inline void printCovarianceReport(const std::vector<int>& tag_ids, const std::vector<double>& cov)
+{
+    double avg[3] = { 0.0, 0.0, 0.0 };
+    for (size_t k = 0; k < tag_ids.size(); ++k) {
+        const double* c = &cov[9 * k];
+        const double sd[3] = { std::sqrt(c[0]), std::sqrt(c[4]), std::sqrt(c[8]) };
+        std::cout << "StdDev of tag " << tag_ids[k] << ": " << sd[0] << " " << sd[1] << " " << sd[2]
+                  << " | StdDevNorm: " << std::sqrt(std::sqrt(sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]))
+                  << std::endl;
+        avg[0] += c[0];
+        avg[1] += c[4];
+        avg[2] += c[8];
+    }
+    const double n = (double)tag_ids.size();
+    std::cout << "Marker Position RMS = " << std::sqrt(avg[0] / n + avg[1] / n + avg[2] / n) << std::endl;
+}
+
 // Body of TagReconstructor::doBundleAdjustment (src/TagReconstructor.cpp:646-743).  Updates the map
 // nodes in place, prints "Solution <termination_type>" like :740.  Returns the termination type.
 template <class TagMap, class CamMap, class Detection, class CamModel>
@@ -159,21 +178,8 @@ int doBundleAdjustment(TagMap& tags, CamMap& cams, const Detection& det, const C
     std::cout << "Solution " << s.termination_type << std::endl;     // :740
     if (printSummary)                                                 // :741-742 (FullReport stand-in)
         printFullReport(s);
-    if (printSummary) {                                               // :761-782
-        double avg[3] = { 0.0, 0.0, 0.0 };
-        for (size_t k = 0; k < p.tag_ids.size(); ++k) {
-            const double* c = &cov[9 * k];
-            const double sd[3] = { std::sqrt(c[0]), std::sqrt(c[4]), std::sqrt(c[8]) };
-            std::cout << "StdDev of tag " << p.tag_ids[k] << ": " << sd[0] << " " << sd[1] << " " << sd[2]
-                      << " | StdDevNorm: " << std::sqrt(std::sqrt(sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]))
-                      << std::endl;
-            avg[0] += c[0];
-            avg[1] += c[4];
-            avg[2] += c[8];
-        }
-        const double n = (double)p.tag_ids.size();
-        std::cout << "Marker Position RMS = " << std::sqrt(avg[0] / n + avg[1] / n + avg[2] / n) << std::endl;
-    }
+    if (printSummary)                                                 // :761-782
+        printCovarianceReport(p.tag_ids, cov);
     return s.termination_type;
 }
 
@@ -269,7 +275,7 @@ public:
     // doBundleAdjustment on the current maps; returns the termination type and prints like the free function
     template <class TagMap, class CamMap>
     int doBundleAdjustment(TagMap& tags, CamMap& cams, int originTagId, int maxNumIterations, size_t ceresThreads,
-                           bool robustify = true)
+                           bool robustify = true, bool printSummary = false)
     {
         if (!prepare(tags, cams, originTagId, true)) {
             std::cout << "Solution " << VMM_BA_CONVERGENCE << std::endl;
@@ -285,6 +291,12 @@ public:
         s.trace_capacity = 0;
         check(vmm_ba_solve(h_, &o, &s), "vmm_ba_solve");
         check(vmm_ba_get_state(h_, cam_qt_.data(), tag_qt_.data()), "vmm_ba_get_state");
+        std::vector<double> cov_all;                                  // :744-760, on the handle that just solved
+        if (printSummary) {
+            cov_all.resize(9 * tag_ids_.size());
+            check(vmm_ba_tag_translation_covariance(h_, o.robustify, o.huber_a, cov_all.data()),
+                  "vmm_ba_tag_translation_covariance");
+        }
         for (auto& kv : cams) {
             if (!cam_active_[cam_index_[kv.first]]) continue;         // :689-690 cameras without reconstructed tags
             const double* q = &cam_qt_[7 * cam_index_[kv.first]];
@@ -297,6 +309,17 @@ public:
             for (int i = 0; i < 3; ++i) kv.second.t(i) = q[4 + i];
         }
         std::cout << "Solution " << s.termination_type << std::endl;  // :740
+        if (printSummary) {                                           // :741-742, :761-782 over the reconstructed tags
+            printFullReport(s);
+            std::vector<int> ids;
+            std::vector<double> cov;
+            for (const auto& kv : tags) {
+                ids.push_back(kv.first);
+                const double* c = &cov_all[9 * tag_index_[kv.first]];
+                cov.insert(cov.end(), c, c + 9);
+            }
+            printCovarianceReport(ids, cov);
+        }
         return s.termination_type;
     }
 

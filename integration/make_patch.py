@@ -9,6 +9,12 @@ The patch is purely additive: the five method bodies it serves --
 -- stay in the files under `#else`; with -DVMM_BA_ROOT=<this repository> CMake defines
 VISUAL_MARKER_MAPPING_WITH_VMM_BA and the bodies become calls into include/vmm_ba_adapter.hpp.
 
+The TagReconstructor owns ONE device-resident handle for its whole life (vmm_ba_adapter::Resident, a guarded
+`mutable std::unique_ptr` next to its other members, include/visual_marker_mapping/TagReconstructor.h:134-145): it is
+built on first use from detectionResults_ and camModel, dropped by setCameraModel, and every one of the N+2 bundle
+adjustments and of the statistics calls of startReconstruction (src/TagReconstructor.cpp:233,236,271-277) only sends
+poses and an observation mask -- no vmm_ba_create per call.
+
 Usage:  python integration/make_patch.py [/root/reference]
 The reference tree is only read; the edits are made on a temporary copy and `diff -u` writes the patch.
 """
@@ -23,26 +29,23 @@ GUARD = "VISUAL_MARKER_MAPPING_WITH_VMM_BA"
 
 BODIES = {
     "const std::map<int, double> TagReconstructor::computeReprojectionErrorPerImg() const": """\
-    return vmm_ba_adapter::reprojectionStatistics(
-        reconstructedTags, reconstructedCameras, detectionResults_, camModel, false).per_img;
+    return vmmBa().reprojectionStatistics(reconstructedTags, reconstructedCameras, originTagId, false).per_img;
 """,
     "const std::map<int, double> TagReconstructor::computeReprojectionErrorPerTag(double& avg) const": """\
-    const auto st = vmm_ba_adapter::reprojectionStatistics(
-        reconstructedTags, reconstructedCameras, detectionResults_, camModel, false);
+    const auto st = vmmBa().reprojectionStatistics(reconstructedTags, reconstructedCameras, originTagId, false);
     avg = st.avg;
     return st.per_tag;
 """,
     "const std::vector<Eigen::Vector2d> TagReconstructor::computeReprojectionErrorPerCorner() const": """\
-    const auto st = vmm_ba_adapter::reprojectionStatistics(
-        reconstructedTags, reconstructedCameras, detectionResults_, camModel, true);
+    const auto st = vmmBa().reprojectionStatistics(reconstructedTags, reconstructedCameras, originTagId, true);
     std::vector<Eigen::Vector2d> out;
     for (const auto& e : st.per_corner)
         out.emplace_back(e[0], e[1]);
     return out;
 """,
     "void TagReconstructor::doBundleAdjustment(": """\
-    vmm_ba_adapter::doBundleAdjustment(reconstructedTags, reconstructedCameras, detectionResults_,
-        camModel, originTagId, maxNumIterations, ceresThreads, robustify, printSummary);
+    vmmBa().doBundleAdjustment(reconstructedTags, reconstructedCameras, originTagId, maxNumIterations, ceresThreads,
+        robustify, printSummary);
 """,
     "Eigen::Vector2d CameraModel::projectPoint(const Eigen::Vector3d& point3D) const": """\
     const auto uv = vmm_ba_adapter::projectPoint(*this, point3D.x(), point3D.y(), point3D.z());
@@ -50,13 +53,47 @@ BODIES = {
 """,
 }
 
+# PUBLIC: the guard adds a member to class TagReconstructor, so every target that includes its header must see it
 CMAKE_BLOCK = """
 # MI355X bundle adjustment: cmake -DVMM_BA_ROOT=<checkout of the libvmm_ba repository>
 if(VMM_BA_ROOT)
-target_compile_definitions(visual_marker_mapping_lib PRIVATE %s)
-target_include_directories(visual_marker_mapping_lib PRIVATE ${VMM_BA_ROOT}/include)
+target_compile_definitions(visual_marker_mapping_lib PUBLIC %s)
+target_include_directories(visual_marker_mapping_lib PUBLIC ${VMM_BA_ROOT}/include)
 target_link_libraries(visual_marker_mapping_lib ${VMM_BA_ROOT}/visual_marker_mapping_amd/libvmm_ba.so)
 endif(VMM_BA_ROOT)
+""" % GUARD
+
+# include/visual_marker_mapping/TagReconstructor.h: the resident handle as a member (behind `CameraModel camModel;`)
+HEADER_MEMBERS = """\
+#ifdef %s
+    // The MI355X engine's device-resident problem (vmm_ba_adapter::Resident<DetectionResult, CameraModel>, defined in
+    // src/TagReconstructor.cpp): built on first use from detectionResults_ and camModel, dropped by setCameraModel.
+    struct VmmBaResident;
+    struct VmmBaResidentDeleter
+    {
+        void operator()(VmmBaResident* p) const;
+    };
+    mutable std::unique_ptr<VmmBaResident, VmmBaResidentDeleter> vmmBaResident_;
+    VmmBaResident& vmmBa() const;
+#endif
+""" % GUARD
+
+# src/TagReconstructor.cpp: the member's definition, in front of the first method that uses it
+SOURCE_RESIDENT = """\
+#ifdef %s
+struct TagReconstructor::VmmBaResident : vmm_ba_adapter::Resident<DetectionResult, CameraModel>
+{
+    using vmm_ba_adapter::Resident<DetectionResult, CameraModel>::Resident;
+};
+void TagReconstructor::VmmBaResidentDeleter::operator()(VmmBaResident* p) const { delete p; }
+TagReconstructor::VmmBaResident& TagReconstructor::vmmBa() const
+{
+    if (!vmmBaResident_)
+        vmmBaResident_.reset(new VmmBaResident(detectionResults_, camModel));
+    return *vmmBaResident_;
+}
+#endif
+//-----------------------------------------------------------------------------
 """ % GUARD
 
 
@@ -81,8 +118,12 @@ def include_adapter(lines, after_prefix):
     lines[last + 1:last + 1] = ["#ifdef %s\n" % GUARD, '#include "vmm_ba_adapter.hpp"\n', "#endif\n"]
 
 
+FILES = ("CMakeLists.txt", "include/visual_marker_mapping/TagReconstructor.h", "src/CameraModel.cpp",
+         "src/TagReconstructor.cpp")
+
+
 def patched_tree(ref, dst):
-    for rel in ("src/TagReconstructor.cpp", "src/CameraModel.cpp", "CMakeLists.txt"):
+    for rel in FILES:
         os.makedirs(os.path.dirname(os.path.join(dst, rel)), exist_ok=True)
         shutil.copy(os.path.join(ref, rel), os.path.join(dst, rel))
     p = os.path.join(dst, "src/TagReconstructor.cpp")
@@ -91,6 +132,21 @@ def patched_tree(ref, dst):
         if "TagReconstructor::" in sig:
             wrap_body(lines, sig, body)
     include_adapter(lines, "#include <")
+    # the resident member's definition in front of the first statistics method
+    k = next(i for i, l in enumerate(lines)
+             if l.startswith("const std::map<int, double> TagReconstructor::computeReprojectionErrorPerImg() const"))
+    lines[k:k] = SOURCE_RESIDENT.splitlines(True)
+    # setCameraModel: another camera model is another device problem
+    k = next(i for i, l in enumerate(lines) if l.startswith("void TagReconstructor::setCameraModel("))
+    k = next(i for i in range(k, len(lines)) if lines[i].strip() == "camModel = cameraModel;")
+    lines[k + 1:k + 1] = ["#ifdef %s\n" % GUARD, "    vmmBaResident_.reset();\n", "#endif\n"]
+    open(p, "w").writelines(lines)
+    p = os.path.join(dst, "include/visual_marker_mapping/TagReconstructor.h")
+    lines = open(p).readlines()
+    k = next(i for i, l in enumerate(lines) if l.strip() == "CameraModel camModel;")
+    lines[k + 1:k + 1] = HEADER_MEMBERS.splitlines(True)
+    k = max(i for i, l in enumerate(lines) if l.startswith("#include <"))
+    lines[k + 1:k + 1] = ["#ifdef %s\n" % GUARD, "#include <memory>\n", "#endif\n"]
     open(p, "w").writelines(lines)
     p = os.path.join(dst, "src/CameraModel.cpp")
     lines = open(p).readlines()
@@ -109,12 +165,12 @@ def patched_tree(ref, dst):
 def make_patch(ref):
     with tempfile.TemporaryDirectory() as tmp:
         a, b = os.path.join(tmp, "a"), os.path.join(tmp, "b")
-        for rel in ("src/TagReconstructor.cpp", "src/CameraModel.cpp", "CMakeLists.txt"):
+        for rel in FILES:
             os.makedirs(os.path.dirname(os.path.join(a, rel)), exist_ok=True)
             shutil.copy(os.path.join(ref, rel), os.path.join(a, rel))
         patched_tree(ref, b)
         text = []
-        for rel in ("CMakeLists.txt", "src/CameraModel.cpp", "src/TagReconstructor.cpp"):
+        for rel in FILES:
             out = subprocess.run(["diff", "-U2", "--label", "a/" + rel, "--label", "b/" + rel, os.path.join("a", rel),
                                   os.path.join("b", rel)], cwd=tmp, stdout=subprocess.PIPE, universal_newlines=True)
             assert out.returncode == 1, (rel, out.returncode)

@@ -8,6 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "adapter_test")
+EXE_INCR = os.path.join(ROOT, "tests", "cpp", "incremental_test")
 
 
 def _scene_text(s, tag_ids, cam_ids):
@@ -23,7 +24,7 @@ def _scene_text(s, tag_ids, cam_ids):
 
 
 def _build():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "all"])
 
 
 def test_adapter_compiles_as_cxx11_and_fails_loudly_without_gpu():
@@ -89,3 +90,28 @@ def test_adapter_matches_python_engine():
     np.testing.assert_array_equal(np.array([tags[t] for t in tag_ids]), tag)
     assert avg == ref_avg and ncorner == 4 * s.n_obs
     np.testing.assert_allclose(uv, eng.project_points(s.intr, s.dist, [[0.3, -0.2, 2.5]])[0], rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_incremental_pattern_through_the_patched_members():
+    """The N + 2 bundle adjustments and the prunings of startReconstruction (src/TagReconstructor.cpp:233,236,271-277)
+    through the members integration/visual_marker_mapping.patch adds to class TagReconstructor (a resident handle,
+    built on first use) against the same sequence with one vmm_ba_create per call: same reconstruction, and the wall
+    time of both (reported by bench.py --workload incremental for the Python mirror)."""
+    _build()
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(5, n_cams=30, n_tags=20, visibility=0.6)
+    tag_ids = [3 + 2 * k for k in range(len(s.tag_init))]
+    cam_ids = [11 + k for k in range(len(s.cam_init))]
+    r = subprocess.run([EXE_INCR], input=_scene_text(s, tag_ids, cam_ids), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    line = next(l for l in r.stdout.splitlines() if l.startswith("INCREMENTAL"))
+    f = line.split()
+    kv = dict(zip(f[1::1], f[2::1]))
+    n_ba = (int(f[2]), int(f[3]))
+    assert n_ba[0] == n_ba[1] == len(cam_ids) + 2
+    assert kv["same_keys"] == "1" and float(kv["maxdiff"]) < 1e-9
+    assert int(kv["cams"]) >= 25 and int(kv["tags"]) >= 15
+    assert r.stdout.count("Solution ") == 2 * (len(cam_ids) + 2)
+    assert r.stdout.count("Marker Position RMS =") == 2          # the final report of both runs (:781)
+    print(line)

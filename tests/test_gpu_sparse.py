@@ -1,0 +1,104 @@
+"""Block-sparse elimination (compressed Z, k_schur_rows) against the dense path and the oracle.
+
+The reference solves with Ceres' sparse normal Cholesky under its ordering (src/TagReconstructor.cpp:725-738) and real
+projects see a handful of tags per image (README.md:155-216).  The dense path stores Z with its zero blocks and
+multiplies them; the block-sparse path keeps only the 6x6 blocks of co-observed (camera, tag) pairs and forms
+S(f, f') -= Z_ef^T Z_ef' over the pairs that share an eliminated pose.  Both are exact: same LM trajectory.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(s, robust, schur, monkeypatch, elim=None, want_cov=False):
+    from visual_marker_mapping_amd import engine as eng
+    if schur is None:
+        monkeypatch.delenv("VMM_BA_SCHUR", raising=False)
+    else:
+        monkeypatch.setenv("VMM_BA_SCHUR", schur)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag,
+                            s.obs_px, elimination=eng.ELIM_AUTO if elim is None else elim)
+    try:
+        out = ba.solve(eng.default_options(robustify=robust), trace_capacity=256)
+        cam, tag = ba.get_state()
+        cov = ba.tag_translation_covariance(robustify=bool(robust)) if want_cov else None
+        out2 = None
+        if want_cov:   # the covariance switched a sparse handle to the dense path and back: it still solves the same way
+            ba.set_state(s.cam_init, s.tag_init)
+            out2 = ba.solve(eng.default_options(robustify=robust))
+    finally:
+        ba.close()
+    return out, cam, tag, cov, out2
+
+
+def _assert_same_run(a, b, ca, ta, cb, tb, rtol=1e-10):
+    assert a["termination_type"] == b["termination_type"] and a["iterations"] == b["iterations"]
+    for x, y in zip(a["trace"], b["trace"]):
+        assert x["step_is_successful"] == y["step_is_successful"]
+        np.testing.assert_allclose(x["cost"], y["cost"], rtol=rtol)
+        np.testing.assert_allclose(x["trust_region_radius"], y["trust_region_radius"], rtol=1e-6)
+    np.testing.assert_allclose(ca, cb, rtol=0, atol=1e-9 * np.abs(cb).max())
+    np.testing.assert_allclose(ta, tb, rtol=0, atol=1e-9 * np.abs(tb).max())
+
+
+SCENES = {
+    "quarter": dict(config=5, n_cams=40, n_tags=30, visibility=0.25),
+    "close_up": dict(config=1, n_cams=60, n_tags=40, neighbors_min=4, neighbors_max=7),
+    "dense": dict(config=1),
+    "far": dict(config=1, n_cams=30, n_tags=20, visibility=0.4, cam_rot_deg=50.0, cam_trans_m=0.8, tag_rot_deg=50.0,
+                tag_trans_m=0.5),
+    # kept family of 250 poses: two column groups in k_schur_rows
+    "two_groups": dict(config=1, n_cams=300, n_tags=250, visibility=0.06),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+@pytest.mark.parametrize("elim", ["cams", "tags"])
+def test_sparse_path_equals_dense_path(monkeypatch, name, elim):
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    kw = dict(SCENES[name])
+    s = make_scene(kw.pop("config"), **kw)
+    robust = 1 if s.robustify else 0
+    mode = eng.ELIM_CAMERAS if elim == "cams" else eng.ELIM_TAGS
+    d, cd, td, covd, _ = _solve(s, robust, "dense", monkeypatch, mode, want_cov=name == "quarter")
+    sp, cs, ts, covs, again = _solve(s, robust, "sparse", monkeypatch, mode, want_cov=name == "quarter")
+    assert d["block_sparse"] == 0 and sp["block_sparse"] == 1
+    assert d["termination_type"] == eng.CONVERGENCE
+    if name == "far":
+        assert d["num_unsuccessful_steps"] >= 1
+    _assert_same_run(sp, d, cs, ts, cd, td)
+    if covd is not None:
+        np.testing.assert_allclose(covs, covd, rtol=1e-7, atol=1e-20)
+        assert again["iterations"] == sp["iterations"] and again["final_cost"] == sp["final_cost"]
+    # fixed summation order: a second run is the same to the bit
+    sp2, cs2, ts2, _, _ = _solve(s, robust, "sparse", monkeypatch, mode)
+    assert sp2["final_cost"] == sp["final_cost"] and np.array_equal(cs, cs2) and np.array_equal(ts, ts2)
+
+
+def test_path_choice_follows_the_block_structure(monkeypatch):
+    """Full visibility keeps the dense MFMA update, a quarter of the pairs or a handful of tags per image goes sparse."""
+    from visual_marker_mapping_amd.synthetic import make_scene
+    for kw, want in ((dict(), 0), (dict(visibility=0.25), 1), (dict(neighbors_min=6, neighbors_max=10), 1)):
+        s = make_scene(2, **kw)
+        out, _, _, _, _ = _solve(s, 0, None, monkeypatch)
+        assert out["block_sparse"] == want, (kw, out["block_sparse"])
+
+
+def test_close_up_full_size_matches_oracle(oracle, monkeypatch):
+    """500 images x 200 tags, every image sees the 6..10 tags nearest to the wall point it stands in front of (4034
+    tag observations, a block-sparse reduced system): trace and solution against the oracle."""
+    from test_gpu_solve import _assert_same_solution, _assert_same_trace
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(2, neighbors_min=6, neighbors_max=10)
+    deg = np.bincount(s.obs_cam, minlength=500)
+    assert deg.min() >= 6 and deg.max() <= 12 and np.bincount(s.obs_tag, minlength=200).min() >= 2
+    out, cam, tag, _, _ = _solve(s, 0, None, monkeypatch)
+    assert out["block_sparse"] == 1 and out["termination_type"] == eng.CONVERGENCE
+    sc = oracle.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+    summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, num_threads=8))
+    _assert_same_trace(out, summ, trace)
+    _assert_same_solution(cam, tag, sc, s.tag_wh)
+    np.testing.assert_array_equal(tag[0], s.tag_init[0])

@@ -10,7 +10,8 @@
  *
  * PRNG: splitmix64, uniforms from the top 53 bits, normals by Box-Muller (both values used).
  * Draw order (fixed): tags 1..N-1 {axis(3n), angle(n), offset(n)}; cameras {az(u), el(u), roll(n),
- * dist(u)}; visibility (u per camera-tag pair, only when visibility < 1); per kept observation
+ * dist(u)} -- with neighbors_min > 0 instead {point x(u), point y(u), count(u), az(u), el(u), roll(n), dist(u)} and no
+ * visibility draws; visibility (u per camera-tag pair, only when visibility < 1); per kept observation
  * 8 noise normals, then (only when outlier_frac > 0) per corner {u, u, u}; initial-guess
  * perturbation: cameras {axis(3n), angle(n), trans(3n)}, tags 1..N-1 likewise.
  */
@@ -30,6 +31,10 @@ typedef struct vmm_scene_cfg {
     int use_distortion;   /* 0: zero distortion; 1: README.md:139-141 coefficients */
     double cam_rot_deg, cam_trans_m; /* initial-guess perturbation sigmas */
     double tag_rot_deg, tag_trans_m;
+    /* > 0: "close-up" scenes like real projects (README.md:155-216: a handful of tags per image) -- every camera
+     * stands in front of a random point of the wall and sees the neighbors_min..neighbors_max tags nearest to it
+     * (`visibility` is ignored).  The reduced systems of such scenes are block-sparse. */
+    int neighbors_min, neighbors_max;
 } vmm_scene_cfg;
 
 typedef struct rng {
@@ -194,15 +199,31 @@ int vmm_scene_generate(const vmm_scene_cfg* cfg, double intr[4], double dist[5],
     const double wall_w = pitch * (gw - 1), wall_h = pitch * (gh - 1);
     const double ctr[3] = { wall_w / 2, wall_h / 2, 0 };
     const double d0 = (wall_w > 0.6 ? wall_w : 0.6) / (2.0 * tan(20.4 * 0.017453292519943295));
+    const int close_up = cfg->neighbors_min > 0;
+    double* look = (double*)malloc(sizeof(double) * 2 * (size_t)nc);   /* wall point each camera looks at */
+    int* n_see = (int*)malloc(sizeof(int) * (size_t)nc);
+    const double d0_close = (4.0 * pitch) / (2.0 * tan(20.4 * 0.017453292519943295));
     for (int c = 0; c < nc; ++c) {
+        double at[3] = { ctr[0], ctr[1], ctr[2] };
+        n_see[c] = nt;
+        if (close_up) {
+            at[0] = uni_ab(&r, 0.0, wall_w);
+            at[1] = uni_ab(&r, 0.0, wall_h);
+            const int span = cfg->neighbors_max - cfg->neighbors_min + 1;
+            n_see[c] = cfg->neighbors_min + (int)(uni(&r) * (span > 0 ? span : 1));
+            if (n_see[c] > nt)
+                n_see[c] = nt;
+        }
+        look[2 * c] = at[0];
+        look[2 * c + 1] = at[1];
         const double az = uni_ab(&r, -35, 35) * 0.017453292519943295;
         const double el = uni_ab(&r, -20, 20) * 0.017453292519943295;
         const double roll = nrm(&r) * 5.0 * 0.017453292519943295;
-        const double dd = uni_ab(&r, 1.25, 1.75) * d0;
+        const double dd = uni_ab(&r, 1.25, 1.75) * (close_up ? d0_close : d0);
         /* camera centre on a viewing cap in front of the wall (+z side) */
-        const double C[3] = { ctr[0] + dd * sin(az) * cos(el), ctr[1] + dd * sin(el),
+        const double C[3] = { at[0] + dd * sin(az) * cos(el), at[1] + dd * sin(el),
                               dd * cos(az) * cos(el) };
-        double f[3] = { ctr[0] - C[0], ctr[1] - C[1], ctr[2] - C[2] };
+        double f[3] = { at[0] - C[0], at[1] - C[1], at[2] - C[2] };
         const double fn = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
         for (int k = 0; k < 3; ++k)
             f[k] /= fn;
@@ -230,7 +251,42 @@ int vmm_scene_generate(const vmm_scene_cfg* cfg, double intr[4], double dist[5],
     /* visibility mask */
     unsigned char* vis = (unsigned char*)malloc((size_t)nc * nt);
     memset(vis, 1, (size_t)nc * nt);
-    if (cfg->visibility < 1.0) {
+    if (close_up) {
+        /* the n_see[c] tags nearest to the point the camera looks at; then every tag in >= 2 images
+         * (TagReconstructor.cpp:189-194), added to the cameras standing nearest to it */
+        memset(vis, 0, (size_t)nc * nt);
+        double* d2 = (double*)malloc(sizeof(double) * (size_t)(nt > nc ? nt : nc));
+        for (int c = 0; c < nc; ++c) {
+            for (int t = 0; t < nt; ++t) {
+                const double dx = tag_gt[7 * t + 4] - look[2 * c], dy = tag_gt[7 * t + 5] - look[2 * c + 1];
+                d2[t] = dx * dx + dy * dy;
+            }
+            for (int k = 0; k < n_see[c]; ++k) {
+                int best = -1;
+                for (int t = 0; t < nt; ++t)
+                    if (!vis[(size_t)c * nt + t] && (best < 0 || d2[t] < d2[best]))
+                        best = t;
+                vis[(size_t)c * nt + best] = 1;
+            }
+        }
+        for (int t = 0; t < nt; ++t) {
+            int n = 0;
+            for (int c = 0; c < nc; ++c) {
+                n += vis[(size_t)c * nt + t];
+                const double dx = tag_gt[7 * t + 4] - look[2 * c], dy = tag_gt[7 * t + 5] - look[2 * c + 1];
+                d2[c] = dx * dx + dy * dy;
+            }
+            while (n < 2 && n < nc) {
+                int best = -1;
+                for (int c = 0; c < nc; ++c)
+                    if (!vis[(size_t)c * nt + t] && (best < 0 || d2[c] < d2[best]))
+                        best = c;
+                vis[(size_t)best * nt + t] = 1;
+                ++n;
+            }
+        }
+        free(d2);
+    } else if (cfg->visibility < 1.0) {
         for (int c = 0; c < nc; ++c)
             for (int t = 0; t < nt; ++t)
                 vis[(size_t)c * nt + t] = uni(&r) < cfg->visibility;
@@ -257,6 +313,8 @@ int vmm_scene_generate(const vmm_scene_cfg* cfg, double intr[4], double dist[5],
     long need = 0;
     for (size_t i = 0; i < (size_t)nc * nt; ++i)
         need += vis[i];
+    free(look);
+    free(n_see);
     if (need > max_obs) {
         free(vis);
         return (int)-need;

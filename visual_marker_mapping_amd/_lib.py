@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VMM_BA_LIB selects another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("VMM_BA_LIB") or os.path.join(_HERE, "libvmm_ba.so")
 
-ABI_VERSION = 2          # VMM_BA_ABI_VERSION of include/vmm_ba.h
+ABI_VERSION = 3          # VMM_BA_ABI_VERSION of include/vmm_ba.h
 RCCL_ID_BYTES = 128      # VMM_BA_RCCL_ID_BYTES
 PRECISION_F64, PRECISION_F32_ACCUM = 0, 1
 LANDMARK_TAG_POSES, LANDMARK_POINTS = 0, 1
@@ -20,7 +20,8 @@ CONVERGENCE, NO_CONVERGENCE, FAILURE = 0, 1, 2
 # every symbol include/vmm_ba.h declares
 EXPORTS = ["vmm_ba_last_error", "vmm_ba_abi_version", "vmm_ba_default_options",
            "vmm_ba_default_create_options", "vmm_ba_create", "vmm_ba_destroy", "vmm_ba_set_state",
-           "vmm_ba_get_state", "vmm_ba_get_points", "vmm_ba_set_allreduce", "vmm_ba_rccl_unique_id", "vmm_ba_enable_rccl",
+           "vmm_ba_get_state", "vmm_ba_get_points", "vmm_ba_set_allreduce", "vmm_ba_rccl_available", "vmm_ba_rccl_unique_id",
+           "vmm_ba_enable_rccl",
            "vmm_ba_set_observation_mask", "vmm_ba_solve", "vmm_ba_cost",
            "vmm_ba_reprojection_stats", "vmm_ba_tag_translation_covariance", "vmm_ba_project_points", "vmm_ba_eval_blocks",
            "vmm_ba_dense_spd_solve", "vmm_ba_dense_syrk", "vmm_ba_time_kernels", "vmm_ba_pose_plus"]
@@ -65,14 +66,17 @@ class Summary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("time_solve_s", C.c_double),
                 ("trace", C.POINTER(Iteration)), ("trace_capacity", C.c_int32), ("reserved", C.c_int32),
                 ("time_eval_s", C.c_double), ("time_eliminate_s", C.c_double), ("time_factor_solve_s", C.c_double),
-                ("time_step_s", C.c_double), ("time_control_s", C.c_double)]
+                ("time_step_s", C.c_double), ("time_control_s", C.c_double),
+                ("num_sync_timeouts", C.c_int32), ("sync_timeout_kernels", C.c_int32),
+                ("block_sparse", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class KernelTimes(C.Structure):
     _fields_ = [("eval_elim_ms", C.c_double), ("eval_keep_ms", C.c_double), ("cost_ms", C.c_double),
                 ("form_z_ms", C.c_double), ("syrk_ms", C.c_double), ("cholesky_ms", C.c_double),
                 ("backsub_ms", C.c_double), ("lm_iteration_ms", C.c_double), ("n_obs", C.c_int64),
-                ("reduced_dim", C.c_int32), ("elim_dim", C.c_int32)]
+                ("reduced_dim", C.c_int32), ("elim_dim", C.c_int32), ("schur_sparse", C.c_int32),
+                ("reserved", C.c_int32), ("schur_flops", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -106,6 +110,8 @@ def lib():
         L.vmm_ba_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.vmm_ba_get_points.argtypes = [C.c_void_p, C.c_void_p]
         L.vmm_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+        L.vmm_ba_rccl_available.restype = C.c_int
+        L.vmm_ba_rccl_available.argtypes = []
         L.vmm_ba_rccl_unique_id.argtypes = [C.c_void_p]
         L.vmm_ba_enable_rccl.argtypes = [C.c_void_p, C.c_void_p]
         L.vmm_ba_set_observation_mask.argtypes = [C.c_void_p, C.c_void_p]

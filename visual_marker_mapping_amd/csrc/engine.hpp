@@ -38,6 +38,7 @@ struct ObsOrder {
     int32_t n_tasks = 0;
     int32_t* pose_task = nullptr;  // [n_pose+1] task range per pose
     double* part = nullptr;        // [n_tasks][kPart]
+    int32_t* start = nullptr;      // [n_pose+1] observation range per pose
 };
 
 // Device control block of the trust-region loop (Ceres TrustRegionMinimizer +
@@ -54,8 +55,17 @@ struct LmCtl {
     double x_cost, cand_cost, model_cost_change, x_norm, initial_cost;
     int32_t iteration;         // index of the iteration record being built
     int32_t first_eval;        // the pending evaluation is iteration zero
-    int32_t done, termination;
-    int32_t lin_fail;          // a Cholesky pivot was not positive in this iteration
+    int32_t done, termination; // done: 0 = running, 1 = the loop is over, 2 = paused: this pass's factorisation gave up
+                               // waiting on another workgroup (sync_timeout), the host redoes it on the launch-per-
+                               // block-column path and resumes (every kernel of a pass returns at once while done != 0)
+    int32_t lin_fail;          // a Cholesky pivot was not positive in this iteration (numerical failures ONLY)
+    // Spin give-ups of the two one-launch kernels that hand data between workgroups.  They are NOT numerical
+    // failures: the trust-region policy never sees them.  sync_timeout: bit 0 k_chol_dataflow, bit 1
+    // k_backsolve_chain, bit 2 another rank reported one (world > 1) -- of the pass that paused; the host clears it.
+    int32_t sync_timeout;
+    int32_t num_sync_timeouts; // passes of this solve redone on the fallback path
+    int32_t sync_kernels;      // OR of sync_timeout over the solve
+    uint32_t spin_limit_df, spin_limit_chain;   // 0 = the kernels' defaults (VMM_BA_DEBUG_SPIN_LIMIT shrinks them)
     int32_t records;           // trace rows pushed (== Ceres summary.iterations.size())
     int32_t num_successful, num_unsuccessful, num_lm_iterations, num_jac_evals, num_cost_evals;
     int32_t trace_capacity;
@@ -140,6 +150,17 @@ struct Engine {
     float* Wf = nullptr;            // the same in f32 (VMM_BA_PRECISION_F32_ACCUM); exactly one of the two exists
     bool f32_accum = false;
 
+    // Fused evaluation (k_eval_fused): one evaluation per observation, lane = kept pose, the wave walks `fused_group`
+    // eliminated poses.  On when most (e, f) pairs are observed (VMM_BA_EVAL=fused|twopass overrides).
+    bool fused_eval = false;
+    int32_t* pair_obs = nullptr;      // [n_e][fused_f_pad]
+    int32_t* fused_e_list = nullptr;  // [fused_n_e_act] eliminated poses with observations
+    int32_t* fused_e_part0 = nullptr; // [n_e] first partial of each eliminated pose
+    int32_t* fused_pose_task = nullptr;   // [n_e + 1] partial range per eliminated pose (k_reduce_pose)
+    double* fused_partE = nullptr;    // [fused_n_e_act * fused_chunks][kPart]
+    double* fused_partF = nullptr;    // [fused_groups][28][fused_f_pad]
+    int fused_n_e_act = 0, fused_f_pad = 0, fused_chunks = 0, fused_group = 1, fused_groups = 0;
+
     // tangent-space vectors, cameras first then tags (6 each)
     double *scale = nullptr, *diag = nullptr, *D2 = nullptr, *delta = nullptr;
     int32_t* active = nullptr;      // per pose (cameras then tags)
@@ -150,6 +171,15 @@ struct Engine {
     double* Z = nullptr;            // [k_pad][ldz] dense L_e^{-1} W (+ z column), row-major
     int k_dim = 0, k_pad = 0;
     int n_red = 0, n_pad = 0, ldz = 0, n_blk = 0;   // reduced order, padded, leading dim, blocks
+    // Block-sparse elimination (kernels_sparse.hip): Z holds only the 6x6 blocks of co-observed (e, f) pairs and
+    // S -= Z^T Z runs over pairs that share an eliminated pose.  Chosen at create by a cost model (VMM_BA_SCHUR=
+    // dense|sparse overrides): at full visibility the dense MFMA rank-k update is the faster one.
+    bool sparse_schur = false;
+    double* Zc = nullptr;           // [36 * n_obs]: per eliminated pose a 6 x 6 deg(e) row-major panel at 36 * start[e]
+    int32_t* f2e = nullptr;         // [n_obs] F-order position -> E-order position of the same observation
+    int32_t* row_items = nullptr;   // [2 * n_row_items] (kept pose, column group) work items of k_schur_rows
+    int n_row_items = 0, row_group_tags = 0;
+    double schur_flops = 0.0;       // algorithmic flops of the reduced-system formation on the path in use
     SyrkPlan syrk;                  // stream-K plan of S = Z^T Z
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
     double* S_packed = nullptr;     // world > 1: rows 0..n_pad of the lower triangle, packed, for the all-reduce
@@ -163,6 +193,10 @@ struct Engine {
     bool no_chain = false;          // VMM_BA_NO_CHAIN=1: per-block back-substitution kernels
     unsigned long long* df_gran = nullptr;   // published 64x8 slices of the dataflow factorisation (<= 21 blocks)
     bool no_dataflow = false;       // VMM_BA_NO_DATAFLOW=1: one k_chol_step launch per block column
+    // debugging: VMM_BA_DEBUG_SPIN_LIMIT=<polls> [VMM_BA_DEBUG_SPIN_KERNEL=df|chain|both] [VMM_BA_DEBUG_SPIN_ONCE=1]
+    // force spin give-ups in the one-launch factorisation / back-substitution (tests/test_gpu_edge_cases.py)
+    uint32_t dbg_spin_df = 0, dbg_spin_chain = 0;
+    bool dbg_spin_once = false;
     double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)
     double* step_comm = nullptr;    // [6*n_e + 2]: delta of the eliminated family | cross term
     double* cost_comm = nullptr;    // [2] candidate cost (all-reduced)
@@ -230,7 +264,8 @@ void launch_pack_lower(Engine& e, bool unpack);
 void launch_syrk_plan(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, const SyrkPlan& p);
 void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int ld, int n_rows, double* S);
 // kernels_chol.hip
-void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl);
+// safe: the launch-per-block-column factorisation and the per-block back-substitution (no workgroup waits on another)
+void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl, bool safe = false);
 void launch_chol_inverse(Engine& e, int k);
 int dataflow_workgroups(int n_blk);   // workgroups of k_chol_dataflow (must all fit on the chip at one per CU)
 // kernels_cov.hip

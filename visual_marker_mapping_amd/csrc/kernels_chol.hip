@@ -656,9 +656,17 @@ __global__ __launch_bounds__(256) void k_backsolve_step(const LmCtl* ctl, double
 // u_m is finished one hop earlier and B_m (a 64x64x64 product) while the workgroup waits for the chain to reach it.
 // (Two blocks per workgroup, 10 hops instead of 19, was built first and changed nothing: the work, not the hand-off,
 // was the larger part of a hop.)
-// Every spin is bounded: on a timeout the solve is flagged as failed (treated like a failed Cholesky
-// by the LM loop) and the flag is still published so that no other workgroup is left waiting.
+// Every spin is bounded: a workgroup that gives up raises LmCtl::sync_timeout (NOT lin_fail: a stalled workgroup is
+// not an indefinite matrix) and pauses the loop (done = 2); it still publishes, so that no other workgroup is left
+// waiting.  The host then redoes this pass's factorisation on the path without inter-workgroup waits.
 constexpr unsigned kSpinLimit = 1u << 22;
+
+// one thread: this pass gave up waiting in kernel `bit` (1 dataflow factorisation, 2 back-substitution chain)
+__device__ __forceinline__ void raise_sync_timeout(LmCtl* ctl, int bit)
+{
+    atomicOr(&ctl->sync_timeout, bit);
+    atomicExch(&ctl->done, 2);
+}
 
 int backsolve_chain_workgroups(int n_blk) { return n_blk; }
 
@@ -683,6 +691,9 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
                                                          unsigned* epoch_word, const double* __restrict__ Ld,
                                                          const double* __restrict__ Linv)
 {
+    // (a give-up inside the dataflow factorisation before this launch has set done = 2: a workgroup that stops
+    // waiting poisons and still publishes, so the factorisation's last workgroup ends after every give-up and sees
+    // the abort word)
     if (ctl->done || ctl->lin_fail) {
         // the factorisation before this launch may have tagged granules with the current epoch: retire it even
         // when the solve is skipped (every workgroup of this launch leaves here, so nobody needs the old value)
@@ -690,6 +701,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
             *epoch_word = *epoch_word + 1u;
         return;
     }
+    const unsigned spin_limit = ctl->spin_limit_chain ? ctl->spin_limit_chain : kSpinLimit;
     __shared__ double L[64 * kLd];    // L(m+1, m) for the product B_m
     __shared__ double Li[64 * kLd];   // Linv_m
     __shared__ double red[4][64];
@@ -714,10 +726,10 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
                 x0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 x1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool ok = (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
-                if (__all(ok))
+                if (__all(ok) && spin_limit != 1u)   // a limit of 1 (debugging) gives up even on valid data
                     break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++n > kSpinLimit) {   // wave-uniform give-up: flagged as a failed linear solve below
+                if (++n >= spin_limit) {   // wave-uniform give-up: reported as a synchronisation time-out below
                     s_timeout = 1;
                     break;
                 }
@@ -857,7 +869,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     CH_RT(m, 2);
     if (tid == 0) {
         if (s_timeout)
-            ctl->lin_fail = 1;
+            raise_sync_timeout(ctl, 2);
         if (m == 0)
             *epoch_word = epoch;   // block 0 is the end of the chain: every other workgroup has read the old value
     }
@@ -962,7 +974,7 @@ __device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, 
 // ends every other spin; the factorisation is then reported as failed (NaN poisoning + lin_fail).
 // ------------------------------------------------------------------------------------------------
 constexpr int kDfSlice = 2 * 8 * 64;         // granules (8 bytes each) per published slice
-constexpr unsigned kDfSpinLimit = 1u << 21;   // polls of ~0.3 us each before giving up
+constexpr unsigned kDfSpinDefault = 1u << 21;   // polls of ~0.3 us each before giving up
 constexpr int kDfXs = 8 * kLdsRow;            // doubles per staged slice, k-major [8][kLdsRow]
 constexpr int kDfSmem = 64 * kLdT + 4 * 64 * kPs + 64 + 4 * kDfXs + 64 * kLd + 64;   // doubles: 107 KB, one workgroup per CU
 
@@ -976,6 +988,7 @@ struct DfArgs {
     unsigned long long* G;       // [n_blk (n_blk + 1) / 2][8][kDfSlice]
     const unsigned* epoch_word;  // bumped by the back-substitution chain that follows
     unsigned* abort_word;        // == epoch: some workgroup gave up waiting
+    unsigned spin_limit;         // polls before a wait gives up (set per launch from LmCtl::spin_limit_df)
 };
 
 __device__ __forceinline__ double df_value(const unsigned long long lo, const unsigned long long hi)
@@ -1173,10 +1186,11 @@ __device__ __forceinline__ bool slice_valid(const SliceRegs& g, const unsigned e
 // direct: the slice is expected any moment (the panel right before mine): sweep it again instead of probing one
 // granule first
 __device__ __forceinline__ bool wait_slice(const unsigned long long* sl, const int lane, const unsigned epoch,
-                                           const unsigned* abort_word, const bool direct, SliceRegs& g)
+                                           const unsigned* abort_word, const bool direct, SliceRegs& g,
+                                           const unsigned kDfSpinLimit)
 {
     for (unsigned n = 0;;) {
-        if (__all(slice_valid(g, epoch)))
+        if (kDfSpinLimit != 1u && __all(slice_valid(g, epoch)))   // a limit of 1 (debugging) gives up even on valid data
             return true;
         if (!direct) {
             for (;;) {
@@ -1184,7 +1198,7 @@ __device__ __forceinline__ bool wait_slice(const unsigned long long* sl, const i
                     = __hip_atomic_load(sl + 512 + 7 * 64 + 63, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(pv >> 32) == epoch)
                     break;
-                if (++n > kDfSpinLimit)
+                if (++n >= kDfSpinLimit)
                     return false;
                 if ((n & 63u) == 0u
                     && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)
@@ -1197,7 +1211,7 @@ __device__ __forceinline__ bool wait_slice(const unsigned long long* sl, const i
                 return false;
             __builtin_amdgcn_s_sleep(1);
         }
-        if (++n > kDfSpinLimit)
+        if (++n >= kDfSpinLimit)
             return false;
         issue_slice(sl, lane, g);
     }
@@ -1337,7 +1351,7 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
         for (int it = 0; it < n_it; ++it) {
             const int k = it >> 3, r = it & 7;
             if (sweeper) {
-                const bool got = wait_slice(sm.at(k, my_rb, r), lane, epoch, a.abort_word, k == j - 1, g);
+                const bool got = wait_slice(sm.at(k, my_rb, r), lane, epoch, a.abort_word, k == j - 1, g, a.spin_limit);
 #ifdef VMM_STAMPS
                 if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 2)
                     g_df_stamps[m.stamp_j][12 + (it - (n_it - 2))] = __builtin_amdgcn_s_memrealtime();
@@ -1538,18 +1552,23 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
                 = make_double2(m.RA[rr * kLd + c], m.RA[rr * kLd + c + 1]);
     }
     if (j == n_blk - 1 && tid == 0) {
+        // a give-up anywhere (the result is NaN-poisoned then, so `ok` says nothing) is a synchronisation failure,
+        // not an indefinite matrix: the pass pauses and the host redoes the factorisation without the dataflow
         const bool aborted = __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-        if (!ok || s_timeout || aborted)
+        if (s_timeout || aborted)
+            raise_sync_timeout(a.ctl, 1);
+        else if (!ok)
             a.ctl->lin_fail = 1;
     }
 }
 
 } // namespace df2
 
-__global__ __launch_bounds__(256) void k_chol_dataflow(const DfArgs a)
+__global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
 {
     if (a.ctl->done)
         return;
+    a.spin_limit = a.ctl->spin_limit_df ? a.ctl->spin_limit_df : kDfSpinDefault;
     phase_stamp(a.ctl, 3);
     if (a.ctl->lin_fail)
         return;
@@ -1621,10 +1640,10 @@ static int update_tiles(int n_blk, int k)   // tiles of the trailing update of p
 
 int dataflow_workgroups(int n_blk) { return n_blk * (n_blk + 1) / 2 + n_blk; }
 
-void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl)
+void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl, bool safe)
 {
     const int n_blk = n_pad / kNB;
-    const bool chain = n_blk <= e.n_cu && e.flags && e.gran && !e.no_chain;
+    const bool chain = n_blk <= e.n_cu && e.flags && e.gran && !e.no_chain && !safe;
     if (chain && e.df_gran && !e.no_dataflow && dataflow_workgroups(n_blk) <= e.n_cu) {
         // one launch for the factorisation + forward substitution, one for the back-substitution chain (which
         // bumps the epoch both kernels tag their granules with)
@@ -1640,6 +1659,7 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         a.G = e.df_gran;
         a.epoch_word = e.flags + 256;
         a.abort_word = e.flags + 257;
+        a.spin_limit = 0;
         hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(n_blk)), dim3(256), 0, e.stream, a);
         hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
                            e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);

@@ -202,10 +202,197 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         eval_body<!E_IS_CAM, false, AT, POINTS>(aF, (int)(((blockIdx.x - nb_e) * blockDim.x + threadIdx.x) >> 6));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused evaluation: every observation is evaluated ONCE (k_eval_both evaluates it twice: in the eliminated family's
+// order for that family's blocks and W, and again in the kept family's order for the kept blocks -- Ceres evaluates
+// TagReconstructionCostFunction, CostFunction.h:101-159, once per residual block).
+//
+// A wave owns 64 kept poses (lane = kept pose f, its pose expanded once per wave) and walks `group` eliminated poses
+// e; the observation of pair (e, f) comes from a lookup table (E-order index or -1).  Per e: the eliminated pose is
+// wave-uniform, the lane evaluates its observation, W goes out, the eliminated family's 28 sums (H 21, g 6, cost) are
+// butterfly-reduced into the partial of (e, chunk) -- exactly the partials of the two-pass kernel when every e sees
+// every f in order.  The kept family's sums stay in the lane's registers across the e's and leave once per wave:
+// partF[group][28][n_f_pad] (SoA: lanes write consecutive doubles), summed over the groups in fixed order by
+// k_reduce_pose.  No atomics, every sum in a fixed order.  Used when most pairs are observed (Engine::fused_eval).
+struct FusedArgs {
+    const int32_t* pair_obs;    // [n_e][n_f_pad] E-order observation index of (e, f), -1: not observed
+    const int32_t* e_list;      // [n_e_act] eliminated poses that own an observation (here: on this rank)
+    const int32_t* e_part0;     // [n_e] first partial slot of pose e (its n_chunks partials are consecutive)
+    int n_e_act, n_f, n_f_pad, n_chunks, group, n_groups;
+    double* partF;              // [n_groups][28][n_f_pad]
+};
+
+template <bool E_IS_CAM, typename AT, bool POINTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_eval_fused(const EvalArgs a, const FusedArgs fa)
+{
+    if (a.ctl) {
+        if (a.ctl->done)
+            return;
+        phase_stamp(a.ctl, 0);
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wave >= fa.n_groups * fa.n_chunks)
+        return;
+    // chunk fastest: the four waves of a workgroup walk the same eliminated poses
+    const int grp = wave / fa.n_chunks, c = wave - grp * fa.n_chunks;
+    const int f = 64 * c + lane;
+    const bool fvalid = f < fa.n_f;
+    const int fs = fvalid ? f : fa.n_f - 1;
+    AT* __restrict__ const Wout = static_cast<AT*>((a.W_alt && a.ctl && a.ctl->w_which == 0) ? a.W_alt : a.W);
+    // the kept pose of this lane: a.other_pose is the kept family here (a = the eliminated family's arguments)
+    const double* keptq = a.other_pose + 7 * (int64_t)fs;
+    Rigid kept;
+    double pt[6];
+    if (POINTS && E_IS_CAM) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            pt[k] = keptq[k];
+    } else if (POINTS) {
+        load_rigid<false>(keptq, kept);   // kept = cameras: UnitQuaternionRotatePoint, the quaternion as it is
+    } else {
+        load_rigid<true>(keptq, kept);
+    }
+    AT HF[21];
+    double gF[6];
+#pragma unroll
+    for (int k = 0; k < 21; ++k)
+        HF[k] = (AT)0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        gF[k] = 0.0;
+    const int e0 = grp * fa.group, e1 = min(e0 + fa.group, fa.n_e_act);
+    for (int ei = e0; ei < e1; ++ei) {
+        const int e = __builtin_amdgcn_readfirstlane(fa.e_list[ei]);
+        const int idx = fvalid ? fa.pair_obs[(int64_t)e * fa.n_f_pad + f] : -1;
+        const bool valid = idx >= 0;
+        const int64_t is = valid ? idx : 0;
+        const int tag_idx = E_IS_CAM ? fs : e;
+        const double* elimq = a.own_pose + 7 * (int64_t)e;   // wave-uniform
+        Rigid elim;
+        if (POINTS && !E_IS_CAM) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                pt[k] = elimq[k];
+        } else if (POINTS) {
+            load_rigid<false>(elimq, elim);
+        } else {
+            load_rigid<true>(elimq, elim);
+        }
+        const Rigid& cam = E_IS_CAM ? elim : kept;
+        const Rigid& tag = E_IS_CAM ? kept : elim;
+        const double* camq = E_IS_CAM ? elimq : keptq;
+        const double hw = POINTS ? 0.0 : 0.5 * a.tag_wh[2 * tag_idx], hh = POINTS ? 0.0 : 0.5 * a.tag_wh[2 * tag_idx + 1];
+        const double tag_on = ((tag_idx >> a.fixed_shift) == a.fixed_tag) ? 0.0 : 1.0;
+        const bool on = valid && a.mask[a.caller[is]];
+        AT H[21];
+        double g[6], cost = 0.0;
+        AT Wacc[36];
+#pragma unroll
+        for (int k = 0; k < 21; ++k)
+            H[k] = (AT)0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            g[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 36; ++k)
+            Wacc[k] = (AT)0;
+#pragma unroll 1
+        for (int cn = 0; cn < (POINTS ? 2 : 4); ++cn) {
+            const double sx = (cn == 1 || cn == 2) ? hw : -hw;
+            const double sy = (cn >= 2) ? hh : -hh;
+            const double u = a.px[(2 * cn) * a.n_pad + is];
+            const double v = a.px[(2 * cn + 1) * a.n_pad + is];
+            CornerEval ce;
+            if (POINTS) {
+                eval_point<true, true>(a.K, cam, camq, pt[3 * cn], pt[3 * cn + 1], pt[3 * cn + 2], u, v, ce, on);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const double j0 = ce.jt[r][0], j1 = ce.jt[r][1], j2 = ce.jt[r][2];
+                    ce.jt[r][0] = cn == 0 ? j0 : 0.0;
+                    ce.jt[r][1] = cn == 0 ? j1 : 0.0;
+                    ce.jt[r][2] = cn == 0 ? j2 : 0.0;
+                    ce.jt[r][3] = cn == 0 ? 0.0 : j0;
+                    ce.jt[r][4] = cn == 0 ? 0.0 : j1;
+                    ce.jt[r][5] = cn == 0 ? 0.0 : j2;
+                }
+            } else {
+                eval_corner<true, true>(a.K, cam, tag, sx, sy, u, v, ce, on);
+            }
+            const double s = ce.ru * ce.ru + ce.rv * ce.rv;
+            double rho0, wgt;
+            huber(a.robustify != 0, a.huber_a, s, rho0, wgt);
+            wgt = on ? wgt : 0.0;
+            cost += on ? 0.5 * rho0 : 0.0;
+            const double w_e = E_IS_CAM ? wgt : wgt * tag_on;   // weight of the eliminated family's columns
+            const double w_f = E_IS_CAM ? wgt * tag_on : wgt;   // ... of the kept family's
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const double res = (r == 0 ? ce.ru : ce.rv) * wgt;   // corrected residual
+                double je[6], jf[6];
+                AT ae[6], af[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    je[k] = (E_IS_CAM ? ce.jc[r][k] : ce.jt[r][k]) * w_e;
+                    jf[k] = (E_IS_CAM ? ce.jt[r][k] : ce.jc[r][k]) * w_f;
+                    ae[k] = (AT)je[k];
+                    af[k] = (AT)jf[k];
+                }
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    g[p] += je[p] * res;
+                    gF[p] += jf[p] * res;
+#pragma unroll
+                    for (int q = 0; q <= p; ++q) {
+                        H[tri(p, q)] += ae[p] * ae[q];
+                        HF[tri(p, q)] += af[p] * af[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        Wacc[6 * p + q] += ae[p] * af[q];
+                }
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 36; ++k)
+                Wout[(int64_t)k * a.n_pad + idx] = Wacc[k];
+        }
+        double red[32];
+#pragma unroll
+        for (int k = 0; k < 21; ++k)
+            red[k] = (double)H[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            red[21 + k] = g[k];
+        red[27] = cost;
+#pragma unroll
+        for (int k = 28; k < 32; ++k)
+            red[k] = 0.0;
+        const double mine = wave_sum32(red, lane);
+        const int slot = wave_sum32_index(lane);
+        if (!(lane & 1) && slot < 28)
+            a.part[(int64_t)(fa.e_part0[e] + c) * kPart + slot] = mine;
+    }
+    if (fvalid) {
+        double* pf = fa.partF + (int64_t)grp * 28 * fa.n_f_pad + f;
+#pragma unroll
+        for (int k = 0; k < 21; ++k)
+            pf[(int64_t)k * fa.n_f_pad] = (double)HF[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            pf[(int64_t)(21 + k) * fa.n_f_pad] = gF[k];
+    }
+}
+
 // Sums the task partials of every pose in task order and expands the packed lower triangle.
 struct ReduceArgs {
     int n_pose;
-    const int32_t* pose_task;
+    const int32_t* pose_task;   // task range per pose; null: every pose has the tasks 0 .. n_fixed-1 (fused kept family)
+    int n_fixed;
+    int64_t st, sk, sp;         // partial (t, k) of pose p at part[t * st + k * sk + p * sp]
     const double* part;
     double* Hout;
     double* gout;
@@ -240,9 +427,22 @@ __global__ void k_reduce_pose(const LmCtl* ctl, const ReduceArgs rE, const Reduc
     const int p = tid >> 5, k = tid & 31;
     if (p >= n_pose || k >= 28)
         return;
-    double s = 0.0;
-    for (int t = pose_task[p]; t < pose_task[p + 1]; ++t)
-        s += part[(int64_t)t * kPart + k];
+    // four interleaved running sums, combined in a fixed order: the loads of a long task list (the fused kernel's
+    // kept family: one partial per group of eliminated poses) do not wait for one another's additions
+    const int t0 = pose_task ? pose_task[p] : 0, t1 = pose_task ? pose_task[p + 1] : r.n_fixed;
+    const double* __restrict__ pp = part + (int64_t)k * r.sk + (int64_t)p * r.sp;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int t = t0;
+    for (; t + 3 < t1; t += 4) {
+        s0 += pp[(int64_t)t * r.st];
+        s1 += pp[(int64_t)(t + 1) * r.st];
+        s2 += pp[(int64_t)(t + 2) * r.st];
+        s3 += pp[(int64_t)(t + 3) * r.st];
+    }
+    if (t < t1) s0 += pp[(int64_t)t * r.st];
+    if (t + 1 < t1) s1 += pp[(int64_t)(t + 1) * r.st];
+    if (t + 2 < t1) s2 += pp[(int64_t)(t + 2) * r.st];
+    const double s = (s0 + s1) + (s2 + s3);
     if (k < 21) {
         int a = 0;
         while ((a + 1) * (a + 2) / 2 <= k)
@@ -525,7 +725,38 @@ void launch_eval_passes(Engine& e, int robustify, double huber_a, bool use_ctl)
     if (!use_ctl)
         aE.ctl = aF.ctl = nullptr;
     const int nb_e = blocks_for_tasks(aE.n_tasks), nb_f = blocks_for_tasks(aF.n_tasks);
-    if (nb_e + nb_f > 0) {
+    if (e.fused_eval) {
+        FusedArgs fa;
+        fa.pair_obs = e.pair_obs;
+        fa.e_list = e.fused_e_list;
+        fa.e_part0 = e.fused_e_part0;
+        fa.n_e_act = e.fused_n_e_act;
+        fa.n_f = e.n_f;
+        fa.n_f_pad = e.fused_f_pad;
+        fa.n_chunks = e.fused_chunks;
+        fa.group = e.fused_group;
+        fa.n_groups = e.fused_groups;
+        fa.partF = e.fused_partF;
+        aE.part = e.fused_partE;
+        const int n_waves = fa.n_groups * fa.n_chunks;
+        const dim3 grid((n_waves + 3) / 4);
+        if (n_waves > 0) {
+            if (e.points) {
+                if (e_is_cam)
+                    hipLaunchKernelGGL((k_eval_fused<true, double, true>), grid, dim3(256), 0, e.stream, aE, fa);
+                else
+                    hipLaunchKernelGGL((k_eval_fused<false, double, true>), grid, dim3(256), 0, e.stream, aE, fa);
+            } else if (e.f32_accum) {
+                if (e_is_cam)
+                    hipLaunchKernelGGL((k_eval_fused<true, float, false>), grid, dim3(256), 0, e.stream, aE, fa);
+                else
+                    hipLaunchKernelGGL((k_eval_fused<false, float, false>), grid, dim3(256), 0, e.stream, aE, fa);
+            } else if (e_is_cam)
+                hipLaunchKernelGGL((k_eval_fused<true, double, false>), grid, dim3(256), 0, e.stream, aE, fa);
+            else
+                hipLaunchKernelGGL((k_eval_fused<false, double, false>), grid, dim3(256), 0, e.stream, aE, fa);
+        }
+    } else if (nb_e + nb_f > 0) {
         if (e.points) {
             if (e_is_cam)
                 hipLaunchKernelGGL((k_eval_both<true, double, true>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, aE, aF, nb_e);
@@ -565,6 +796,20 @@ void launch_eval_passes(Engine& e, int robustify, double huber_a, bool use_ctl)
     rF.n_pose = e.n_f;
     rF.pose_task = e.ordF.pose_task;
     rF.part = e.ordF.part;
+    rE.n_fixed = rF.n_fixed = 0;
+    rE.st = rF.st = kPart;
+    rE.sk = rF.sk = 1;
+    rE.sp = rF.sp = 0;
+    if (e.fused_eval) {
+        rE.pose_task = e.fused_pose_task;
+        rE.part = e.fused_partE;
+        rF.pose_task = nullptr;           // every kept pose: one partial per group of eliminated poses
+        rF.n_fixed = e.fused_groups;
+        rF.part = e.fused_partF;
+        rF.st = 28 * (int64_t)e.fused_f_pad;
+        rF.sk = e.fused_f_pad;
+        rF.sp = 1;
+    }
     rF.Hout = e_is_cam ? oH_tag : oH_cam;
     rF.gout = e_is_cam ? og_tag : og_cam;
     rF.pose_cost = nullptr;
@@ -666,6 +911,12 @@ int preload_eval_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, float>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<true, double, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_both<false, double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_fused<true, double, false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_fused<false, double, false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_fused<true, float, false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_fused<false, float, false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_fused<true, double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_eval_fused<false, double, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cost<true, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_cost<false, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_pose)) != hipSuccess;

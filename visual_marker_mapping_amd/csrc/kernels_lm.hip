@@ -475,7 +475,9 @@ __device__ __forceinline__ void candidate_for_pose(const PoseViews& pv, const in
 // One wave per eliminated pose.
 // FUSE (one GPU): the candidate of every pose is formed here too -- an eliminated pose's by lane 0 of its wave, the
 // kept poses' by one thread each in the workgroups behind the eliminated family's -- instead of in k_candidate.
-template <bool FUSE>
+// SPARSE: Z is the compressed Engine::Zc (a 6 x 6 deg(e) panel per eliminated pose); the product with y_f gathers
+// the kept poses of e's observations.
+template <bool FUSE, bool SPARSE>
 __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose,
                                                  const int32_t* __restrict__ pose_task,
                                                  const double* __restrict__ Z, int ldz, int n_red,
@@ -486,8 +488,14 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
                                                  double* __restrict__ delta, const double* __restrict__ H0,
                                                  const double* __restrict__ g0, const int64_t alt_off,
                                                  const int32_t* __restrict__ active,
-                                                 double* __restrict__ pose_part)
+                                                 double* __restrict__ pose_part,
+                                                 const int32_t* __restrict__ e_start,
+                                                 const int32_t* __restrict__ e_other)
 {
+    // world > 1: this rank's vote on "the factorisation of this pass gave up waiting" rides on the step all-reduce
+    // (slot 6 n_e + 1; slot 6 n_e is the cross term), so that all ranks pause in the same pass (k_candidate)
+    if (!FUSE && blockIdx.x == 0 && threadIdx.x == 0)
+        step_comm[6 * (int64_t)n_e + 1] = (ctl->done == 2) ? 1.0 : 0.0;
     if (ctl->done)
         return;
     phase_stamp(ctl, 4);
@@ -529,14 +537,26 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
     }
     __shared__ double s_acc[4][6];
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
-    const double* zr = Z + (int64_t)(6 * e) * ldz;
-    // 16-byte loads: n_red = 6 n_f is even and every row of Z starts 16-byte aligned (ldz is even)
-    for (int c = 2 * (int)threadIdx.x; c < n_red; c += 512) {
-        const double2 yv = *reinterpret_cast<const double2*>(yf + c);
+    if (SPARSE) {
+        const int es = e_start[e], rs = 6 * (e_start[e + 1] - es);
+        const double* zp = Z + 36 * (int64_t)es;
+        for (int t = (int)threadIdx.x; t < rs; t += 256) {
+            const int k = t / 6, c = t - 6 * k;
+            const double yv = yf[6 * (int64_t)e_other[es + k] + c];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double2 zv = *reinterpret_cast<const double2*>(zr + (int64_t)i * ldz + c);
-            acc[i] += zv.x * yv.x + zv.y * yv.y;
+            for (int i = 0; i < 6; ++i)
+                acc[i] += zp[i * rs + t] * yv;
+        }
+    } else {
+        const double* zr = Z + (int64_t)(6 * e) * ldz;
+        // 16-byte loads: n_red = 6 n_f is even and every row of Z starts 16-byte aligned (ldz is even)
+        for (int c = 2 * (int)threadIdx.x; c < n_red; c += 512) {
+            const double2 yv = *reinterpret_cast<const double2*>(yf + c);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double2 zv = *reinterpret_cast<const double2*>(zr + (int64_t)i * ldz + c);
+                acc[i] += zv.x * yv.x + zv.y * yv.y;
+            }
         }
     }
 #pragma unroll
@@ -584,13 +604,21 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
 }
 
 // World > 1 (the eliminated family's step is all-reduced first): the candidate of every pose in a launch of its own.
-__global__ void k_candidate(const LmCtl* ctl, PoseViews pv, int n_e, int e_off_pose, int f_off_pose,
+__global__ void k_candidate(LmCtl* ctl, PoseViews pv, int n_e, int e_off_pose, int f_off_pose,
                             const double* __restrict__ step_comm, const double* __restrict__ yf,
                             const double* __restrict__ scale, double* __restrict__ delta,
                             const double* __restrict__ H, const double* __restrict__ g,
                             const int32_t* __restrict__ active, double* __restrict__ pose_part)
 {
-    if (ctl->done)
+    // the summed votes of k_backsub: some rank's factorisation gave up waiting in this pass -> every rank pauses here
+    // (the ranks must take the same decisions and make the same collective calls; the hosts redo the pass together)
+    const bool remote = step_comm[6 * (int64_t)n_e + 1] > 0.0;
+    if (remote && blockIdx.x == 0 && threadIdx.x == 0 && ctl->done != 1) {
+        if (ctl->done == 0)
+            atomicOr(&ctl->sync_timeout, 4);
+        atomicExch(&ctl->done, 2);
+    }
+    if (ctl->done || remote)
         return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_pose = pv.n_cams + pv.n_tags;
@@ -716,16 +744,25 @@ void launch_backsub(Engine& e)
     const int e_off = e.elim_cams ? 0 : e.n_cams;
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const int nb_e = e.n_e;   // one workgroup per eliminated pose
+    const double* const Zp = e.sparse_schur ? e.Zc : e.Z;
+#define VMM_BACKSUB(FUSE, SP, GRID)                                                                                      \
+    hipLaunchKernelGGL((k_backsub<FUSE, SP>), dim3(GRID), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,   \
+                       Zp, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off, e.n_f,  \
+                       nb_e, e.delta, e.H_cam, e.g_cam, e.small_alt_off, e.active, e.pose_part,                           \
+                       (const int32_t*)e.ordE.start, (const int32_t*)e.ordE.other)
     if (e.multi) {
-        hipLaunchKernelGGL((k_backsub<false>), dim3(nb_e), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
-                           e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off,
-                           e.n_f, nb_e, e.delta, e.H_cam, e.g_cam, e.small_alt_off, e.active, e.pose_part);
+        if (e.sparse_schur)
+            VMM_BACKSUB(false, true, nb_e);
+        else
+            VMM_BACKSUB(false, false, nb_e);
         return;
     }
     const int nb_f = (e.n_f + 255) / 256;
-    hipLaunchKernelGGL((k_backsub<true>), dim3(nb_e + nb_f), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,
-                       e.Z, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off, e.n_f,
-                       nb_e, e.delta, e.H_cam, e.g_cam, e.small_alt_off, e.active, e.pose_part);
+    if (e.sparse_schur)
+        VMM_BACKSUB(true, true, nb_e + nb_f);
+    else
+        VMM_BACKSUB(true, false, nb_e + nb_f);
+#undef VMM_BACKSUB
 }
 
 void launch_candidate(Engine& e)
@@ -747,8 +784,10 @@ int preload_lm_kernels()
     int bad = 0;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_control)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_begin_loop)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<true>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<true, false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<false, false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<true, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsub<false, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_candidate)) != hipSuccess;
     return bad;
 }

@@ -51,7 +51,9 @@ __device__ __forceinline__ bool chol6(double* A)
 // observation stores L_e, z_e and the rhs column of Z.  A pose without observations owns no thread: nobody reads
 // its L_e, and its rows of Z (zero since vmm_ba_create) stay zero -- also what a rank needs for a pose whose
 // observations live on another rank.
-template <typename WT>
+// SPARSE: the block goes into the compressed Z (Engine::Zc: per eliminated pose a 6 x 6 deg(e) row-major panel at
+// 36 * start[e], the pose's observations in E order) instead of into the dense matrix, and the rhs lives in ze only.
+template <typename WT, bool SPARSE>
 __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64_t n_pad,
                                                  const int32_t* __restrict__ own,
                                                  const int32_t* __restrict__ other,
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64
                                                  const double* __restrict__ D2,
                                                  double* __restrict__ Le, double* __restrict__ ze,
                                                  const double* __restrict__ scale, int e_off_pose,
-                                                 int f_off_pose, double* __restrict__ Z, int ldz, int zcol)
+                                                 int f_off_pose, double* __restrict__ Z, int ldz, int zcol,
+                                                 const int32_t* __restrict__ e_start)
 {
     if (ctl->done)
         return;
@@ -110,7 +113,8 @@ __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             ze[6 * (int64_t)e + k] = v[k];
-            Z[(int64_t)(6 * e + k) * ldz + zcol] = v[k];
+            if (!SPARSE)
+                Z[(int64_t)(6 * e + k) * ldz + zcol] = v[k];
         }
     }
     double X[36];
@@ -131,12 +135,18 @@ __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64
             X[6 * r + c] = t * inv;
         }
     }
+    int64_t rs = ldz;
     double* zrow = Z + (int64_t)(6 * e) * ldz + 6 * f;
+    if (SPARSE) {
+        const int es = e_start[e];
+        rs = 6 * (int64_t)(e_start[e + 1] - es);
+        zrow = Z + 36 * (int64_t)es + 6 * (i - es);
+    }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c < 6; ++c)
-            zrow[(int64_t)r * ldz + c] = X[6 * r + c];
+            zrow[(int64_t)r * rs + c] = X[6 * r + c];
 }
 
 // ---- symmetric rank-k update on the f64 matrix cores --------------------------------------------
@@ -377,6 +387,155 @@ __global__ void k_add_diag(const LmCtl* ctl, int n_f, int f_off_pose, const doub
     }
 }
 
+
+// ---- block-sparse reduced system: S(f, f') -= sum over the eliminated poses e that see both f and f' --------------
+//
+// The dense path stores Z with its zero blocks and multiplies them (at 25 % visibility 15/16 of the rank-k flops);
+// here Z holds only the blocks of co-observed pairs (Engine::Zc) and the product runs over pairs that share an e --
+// what the sparse normal-Cholesky behind ceres::Solve (src/TagReconstructor.cpp:725-738) exploits on projects where an
+// image sees a handful of tags (README.md:155-216).  No atomics, fixed summation order:
+//   * one workgroup per (kept pose f, column group): its LDS holds the 6 rows of S that belong to f for the group's
+//     columns (f' <= f: lower triangle), accumulated over the poses e that see f, in the order of f's observations;
+//   * for one e the 36 entries of Z_ef are wave-uniform (scalar registers), a lane owns one column (f', c) of e's
+//     panel: six loads, 36 multiply-adds, six read-modify-writes of the LDS accumulator;
+//   * column f' belongs to wave f' & 3 of the workgroup for the whole kernel, so no two waves ever touch the same
+//     accumulator entry and every entry is summed in e order: bit-repeatable.  A wave finds its columns of e with one
+//     ballot over e's neighbour list (any order, any length).
+// The group's rows are written once, with the kept family's damped diagonal block and right-hand side (one GPU), and
+// with zeros up to the next 64-column boundary: the Cholesky kernels load whole 16x16 tiles of the diagonal blocks.
+struct RowArgs {
+    const LmCtl* ctl;
+    const int32_t* items;       // [n_items][2]: kept pose (n_f = the padding rows), column group
+    int group_tags;             // tags per column group (accumulator: 6 x 6 group_tags doubles)
+    int n_f;
+    const int32_t* f_start;     // [n_f + 1] F-order observation range of every kept pose
+    const int32_t* f_other;     // [n_obs]  F order: the eliminated pose
+    const int32_t* f2e;         // [n_obs]  F order -> E-order position
+    const int32_t* e_start;     // [n_e + 1]
+    const int32_t* e_other;     // [n_obs]  E order: the kept pose
+    const double* Zc;
+    const double* ze;
+    double* S;
+    int ld;
+    DiagArgs da;
+    int add_diag;
+};
+
+__global__ __launch_bounds__(256, 2) void k_schur_rows(RowArgs a)
+{
+    if (a.ctl && a.ctl->done)
+        return;
+    extern __shared__ __attribute__((aligned(16))) double rows_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = a.items[2 * blockIdx.x], g = a.items[2 * blockIdx.x + 1];
+    const int n_red = a.da.n_red, n_pad = a.da.n_pad, ld = a.ld;
+    if (f >= a.n_f) {
+        // padding of the reduced system: rows n_red .. n_pad-1 = unit rows (one GPU; world > 1: zero, k_add_diag sets
+        // the ones behind the all-reduce), and the right-hand side's padding entries
+        for (int i = n_red + (tid >> 6); i < n_pad; i += 4)
+            for (int j = lane; j < n_pad; j += 64)
+                a.S[(int64_t)i * ld + j] = (a.add_diag && i == j) ? 1.0 : 0.0;
+        for (int j = n_red + tid; j < n_pad; j += 256)
+            a.S[(int64_t)n_pad * ld + j] = 0.0;
+        return;
+    }
+    const int lo = g * a.group_tags;
+    const int hi = min(lo + a.group_tags, f + 1);   // columns f' in [lo, hi): the lower triangle ends at f
+    const int W = 6 * a.group_tags;
+    double* acc = rows_smem;                                             // [6][W]
+    int* slist = reinterpret_cast<int*>(rows_smem + 6 * W) + w * 128;    // this wave's [64] slots | [64] columns
+    for (int i = tid; i < 6 * W; i += 256)
+        acc[i] = 0.0;
+    __syncthreads();
+    const double* __restrict__ Zc = a.Zc;
+    double bacc = 0.0;   // wave 0, lanes 0..5 of group 0: (Z^T z)_f
+    const int i0 = a.f_start[f], i1 = a.f_start[f + 1];
+    for (int idx = i0; idx < i1; ++idx) {
+        const int e = __builtin_amdgcn_readfirstlane(a.f_other[idx]);
+        const int ie = __builtin_amdgcn_readfirstlane(a.f2e[idx]);
+        const int es = __builtin_amdgcn_readfirstlane(a.e_start[e]);
+        const int deg = __builtin_amdgcn_readfirstlane(a.e_start[e + 1]) - es;
+        const int rs = 6 * deg;
+        const double* __restrict__ P = Zc + 36 * (int64_t)es;      // e's panel: 6 rows of 6 deg doubles
+        const double* __restrict__ Pf = P + 6 * (ie - es);         // Z_ef: wave-uniform
+        double A[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                A[r][q] = Pf[r * rs + q];
+        if (g == 0 && w == 0 && lane < 6) {
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                t += Pf[r * rs + lane] * a.ze[6 * (int64_t)e + r];
+            bacc += t;
+        }
+        for (int base = 0; base < deg; base += 64) {
+            const int slot = base + lane;
+            const int fp = slot < deg ? a.e_other[es + slot] : -1;
+            const bool own = fp >= lo && fp < hi && (fp & 3) == w;
+            const unsigned long long mask = __ballot(own);
+            const int cnt = __popcll(mask);
+            if (cnt == 0)
+                continue;
+            if (own) {
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                slist[rank] = slot;
+                slist[64 + rank] = fp - lo;
+            }
+            __builtin_amdgcn_wave_barrier();   // same wave, LDS in issue order: the list is complete for the reads below
+            for (int t0 = 0; t0 < 6 * cnt; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < 6 * cnt) {
+                    const int k = t / 6, c = t - 6 * k;
+                    const double* __restrict__ bp = P + 6 * slist[k] + c;
+                    double b[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+                        b[r] = bp[r * rs];
+                    double* ap = acc + 6 * slist[64 + k] + c;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        double o = A[0][q] * b[0];
+#pragma unroll
+                        for (int r = 1; r < 6; ++r)
+                            o = fma(A[r][q], b[r], o);
+                        ap[q * W] += o;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the list is overwritten by the next chunk
+        }
+    }
+    __syncthreads();
+    if (a.add_diag && a.ctl) {
+        a.da.H_F += small_sel(a.ctl, a.da.alt_off);
+        a.da.g_F += small_sel(a.ctl, a.da.alt_off);
+    }
+    // the group's columns of rows 6f .. 6f+5; the last group also zeroes the rest of the diagonal 64-block
+    const bool last = hi == f + 1;
+    const int c0 = 6 * lo, c1 = last ? min(((6 * f + 6 + 63) / 64) * 64, ld) : 6 * hi;
+    const int ncol = c1 - c0;
+    for (int i = tid; i < 6 * ncol; i += 256) {
+        const int q = i / ncol, col = i - q * ncol;
+        const int gcol = c0 + col, row = 6 * f + q;
+        double v = (gcol < 6 * hi) ? -acc[q * W + col] : 0.0;
+        if (a.add_diag && gcol >= 6 * f && gcol < 6 * f + 6) {
+            const int b = gcol - 6 * f;
+            v += a.da.scale_F[row] * a.da.H_F[36 * (int64_t)f + 6 * q + b] * a.da.scale_F[gcol];
+            if (q == b)
+                v += a.da.D2_F[row];
+        }
+        a.S[(int64_t)row * ld + gcol] = v;
+    }
+    if (g == 0 && w == 0 && lane < 6) {
+        const int col = 6 * f + lane;
+        a.S[(int64_t)n_pad * ld + col] = (a.add_diag ? a.da.scale_F[col] * a.da.g_F[col] : 0.0) - bacc;
+    }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------
 
 static SyrkPlanDev plan_dev(const SyrkPlan& p)
@@ -403,14 +562,23 @@ void launch_elim(Engine& e)
     const double* g_E = e.elim_cams ? e.g_cam : e.g_tag;
     if (e.ordE.n > 0) {
         const dim3 grid((unsigned)((e.ordE.n + 255) / 256));
-        if (e.f32_accum)
-            hipLaunchKernelGGL((k_form_z<float>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,
-                               e.ordE.other, (const float*)e.Wf, (const float*)e.Wf2, H_E, g_E, e.small_alt_off, (const double*)e.D2, e.Le, e.ze, e.scale, e_off,
-                               f_off, e.Z, e.ldz, e.n_pad);
-        else
-            hipLaunchKernelGGL((k_form_z<double>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,
-                               e.ordE.other, (const double*)e.W, (const double*)e.W2, H_E, g_E, e.small_alt_off, (const double*)e.D2, e.Le, e.ze, e.scale, e_off,
-                               f_off, e.Z, e.ldz, e.n_pad);
+        double* const Zout = e.sparse_schur ? e.Zc : e.Z;
+#define VMM_FORM_Z(WT, SP, W0, W1)                                                                                      \
+    hipLaunchKernelGGL((k_form_z<WT, SP>), grid, dim3(256), 0, e.stream, e.ctl, e.ordE.n, e.ordE.n_pad, e.ordE.own,      \
+                       e.ordE.other, (const WT*)(W0), (const WT*)(W1), H_E, g_E, e.small_alt_off, (const double*)e.D2,   \
+                       e.Le, e.ze, e.scale, e_off, f_off, Zout, e.ldz, e.n_pad, (const int32_t*)e.ordE.start)
+        if (e.f32_accum) {
+            if (e.sparse_schur)
+                VMM_FORM_Z(float, true, e.Wf, e.Wf2);
+            else
+                VMM_FORM_Z(float, false, e.Wf, e.Wf2);
+        } else {
+            if (e.sparse_schur)
+                VMM_FORM_Z(double, true, e.W, e.W2);
+            else
+                VMM_FORM_Z(double, false, e.W, e.W2);
+        }
+#undef VMM_FORM_Z
     }
 }
 
@@ -428,13 +596,52 @@ void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int
                            S, da);
 }
 
-void launch_syrk_only(Engine& e) { launch_syrk_plan(e.stream, e.ctl, e.Z, e.ldz, e.syrk); }
+void launch_schur_rows(Engine& e, bool add_diag)
+{
+    if (e.n_row_items <= 0)
+        return;
+    const int f_off = e.elim_cams ? e.n_cams : 0;
+    RowArgs a;
+    a.ctl = e.ctl;
+    a.items = e.row_items;
+    a.group_tags = e.row_group_tags;
+    a.n_f = e.n_f;
+    a.f_start = e.ordF.start;
+    a.f_other = e.ordF.other;
+    a.f2e = e.f2e;
+    a.e_start = e.ordE.start;
+    a.e_other = e.ordE.other;
+    a.Zc = e.Zc;
+    a.ze = e.ze;
+    a.S = e.S;
+    a.ld = e.ldz;
+    a.da.H_F = e.elim_cams ? e.H_tag : e.H_cam;
+    a.da.g_F = e.elim_cams ? e.g_tag : e.g_cam;
+    a.da.scale_F = e.scale + 6 * (size_t)f_off;
+    a.da.D2_F = e.D2 + 6 * (size_t)f_off;
+    a.da.n_red = e.n_red;
+    a.da.n_pad = e.n_pad;
+    a.da.alt_off = e.small_alt_off;
+    a.add_diag = add_diag ? 1 : 0;
+    const size_t lds = sizeof(double) * 36 * (size_t)e.row_group_tags + sizeof(int) * 4 * 128;
+    hipLaunchKernelGGL(k_schur_rows, dim3(e.n_row_items), dim3(256), lds, e.stream, a);
+}
+
+void launch_syrk_only(Engine& e)
+{
+    if (e.sparse_schur)
+        launch_schur_rows(e, !e.multi);
+    else
+        launch_syrk_plan(e.stream, e.ctl, e.Z, e.ldz, e.syrk);
+}
 
 // S = -(sum of partials) [+ damped diagonal blocks and rhs on one GPU; with world > 1 they are added by
 // launch_add_diag after the all-reduce, being identical on every rank]
 void launch_syrk_reduced(Engine& e)
 {
     launch_syrk_only(e);
+    if (e.sparse_schur)
+        return;   // k_schur_rows writes S itself (with the diagonal blocks on one GPU)
     if (e.multi) {
         launch_reduce_plan(e.stream, e.ctl, e.syrk, e.ldz, e.n_pad + 1, e.S);
         return;
@@ -497,8 +704,11 @@ int preload_schur_kernels()
 {
     hipFuncAttributes at;
     int bad = 0;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<double>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<float>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<double, false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<float, false>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<double, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<float, true>)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_schur_rows)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_syrk_streamk)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<false>)) != hipSuccess;

@@ -121,10 +121,30 @@ static Rccl& rccl()
     return r;
 }
 
+// VMM_BA_DEBUG_SPIN_LIMIT=<polls> [VMM_BA_DEBUG_SPIN_KERNEL=df|chain|both] [VMM_BA_DEBUG_SPIN_ONCE=1]: shrink the bounded
+// spins of k_chol_dataflow / k_backsolve_chain so that they give up (tests of the recovery path only).  A limit of 1
+// makes every wait give up at its first poll, arrived data or not: every pass is then redone, deterministically.
+static void read_spin_debug_env(Engine& e)
+{
+    const char* sl = getenv("VMM_BA_DEBUG_SPIN_LIMIT");
+    if (!sl)
+        return;
+    const unsigned lim = (unsigned)std::max(1L, atol(sl));
+    const char* sk = getenv("VMM_BA_DEBUG_SPIN_KERNEL");
+    const std::string which = sk ? sk : "both";
+    if (which == "df" || which == "both")
+        e.dbg_spin_df = lim;
+    if (which == "chain" || which == "both")
+        e.dbg_spin_chain = lim;
+    const char* so = getenv("VMM_BA_DEBUG_SPIN_ONCE");
+    e.dbg_spin_once = so && so[0] == '1';
+}
+
 // Sorts the observations by one pose family (stable counting sort) and cuts each pose's run into
 // wave-sized tasks.
 static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx, const int32_t* other_idx,
-                       const double* px, int64_t n)
+                       const double* px, int64_t n, std::vector<int32_t>* caller_out = nullptr,
+                       std::vector<int32_t>* start_out = nullptr, std::vector<int32_t>* other_out = nullptr)
 {
     std::vector<int64_t> start((size_t)n_own + 1, 0);
     for (int64_t i = 0; i < n; ++i)
@@ -167,6 +187,9 @@ static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx
     if ((rc = dev_alloc(e, &o.tasks, tasks.size()))) return rc;
     if ((rc = dev_alloc(e, &o.pose_task, pose_task.size()))) return rc;
     if ((rc = dev_alloc(e, &o.part, tasks.size() * kPart))) return rc;
+    std::vector<int32_t> start32(start.begin(), start.end());
+    if ((rc = dev_alloc(e, &o.start, start32.size()))) return rc;
+    if ((rc = upload(e, o.start, start32))) return rc;
     if ((rc = upload(e, o.own, own))) return rc;
     if ((rc = upload(e, o.other, other))) return rc;
     if ((rc = upload(e, o.caller, caller))) return rc;
@@ -174,6 +197,12 @@ static int build_order(Engine& e, ObsOrder& o, int n_own, const int32_t* own_idx
     if ((rc = upload(e, o.tasks, tasks))) return rc;
     if ((rc = upload(e, o.pose_task, pose_task))) return rc;
     HIP_TRY(hipStreamSynchronize(e.stream));  // host vectors go out of scope
+    if (caller_out)
+        caller_out->swap(caller);
+    if (start_out)
+        start_out->swap(start32);
+    if (other_out)
+        other_out->swap(other);
     return VMM_BA_OK;
 }
 
@@ -430,6 +459,18 @@ static std::vector<double> pairs_from_tags(const double* tag_qt, const double* t
     return pairs;
 }
 
+// Dense Z and the plan of its rank-k update (the default at high visibility; a handle on the block-sparse path
+// builds them the first time the covariance report asks for Z as a matrix).
+static int ensure_dense_schur(Engine& e)
+{
+    if (e.Z)
+        return VMM_BA_OK;
+    int rc;
+    if ((rc = dev_alloc(e, &e.Z, (size_t)e.k_pad * e.ldz))) return rc;
+    // 128-row blocks covering rows 0..n_pad (the last one holds the rhs row) and columns 0..n_pad-1
+    return make_syrk_plan(e, e.syrk, (e.n_pad + kST) / kST, (e.n_pad + kST - 1) / kST, e.k_pad);
+}
+
 static int do_allreduce(Engine& e, double* buf, size_t count)
 {
     if (!e.multi)
@@ -452,6 +493,27 @@ static int do_allreduce(Engine& e, double* buf, size_t count)
         set_error("all-reduce callback failed");
         return VMM_BA_ERR_COLLECTIVE;
     }
+    return VMM_BA_OK;
+}
+
+// World > 1 with the library's own communicator: the ranks agree (minimum) on a yes/no each of them holds, with an
+// eager ncclAllReduce on the engine's stream.  Used where a per-rank decision would make the ranks enqueue different
+// sequences of collectives (graph or no graph: ADVICE.md round 2).
+static int rccl_agree(Engine& e, bool mine, bool* all)
+{
+    unsigned* word = e.flags + 258;
+    const unsigned v = mine ? 1u : 0u;
+    unsigned out = 0;
+    HIP_TRY(hipMemcpyAsync(word, &v, sizeof(v), hipMemcpyHostToDevice, e.stream));
+    const ncclResult_t r = rccl().AllReduce(word, word, 1, ncclUint32, ncclMin, reinterpret_cast<ncclComm_t>(e.rccl_comm),
+                                            e.stream);
+    if (r != ncclSuccess) {
+        set_error(std::string("ncclAllReduce (agreement): ") + rccl().GetErrorString(r));
+        return VMM_BA_ERR_COLLECTIVE;
+    }
+    HIP_TRY(hipMemcpyAsync(&out, word, sizeof(out), hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    *all = out != 0;
     return VMM_BA_OK;
 }
 
@@ -491,22 +553,28 @@ static void destroy_engine(Engine* e)
 // pass, and the accept/reject decision sits directly in front of the next iteration's set-up.  A rejected step
 // wastes the Jacobian part of its evaluation (21 us of a 0.5 ms iteration at 500 x 200).
 constexpr int kNumSeg = 4;
-static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg)
+// redo: the host's recovery of a pass whose one-launch factorisation gave up waiting (LmCtl::sync_timeout): the
+// reduced system is rebuilt from Z (the factorisation overwrote it) and factored on the path without
+// inter-workgroup waits; the control kernel and the elimination of that pass have run and are not repeated.
+static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg, bool redo = false)
 {
     switch (seg) {
     case 0:
-        launch_eval_passes(e, o.robustify, o.huber_a, true);
+        if (!redo)
+            launch_eval_passes(e, o.robustify, o.huber_a, true);
         break;
     case 1:
-        launch_control(e);
-        launch_elim(e);
+        if (!redo) {
+            launch_control(e);
+            launch_elim(e);
+        }
         launch_syrk_reduced(e);
         launch_pack_lower(e, false);
         break;
     case 2:
         launch_pack_lower(e, true);
         launch_add_diag(e);
-        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
+        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl, redo);
         launch_backsub(e);
         if (e.multi)
             launch_sum(e, true, e.part_cross, e.n_e, e.step_comm + 6 * (size_t)e.n_e);
@@ -523,7 +591,7 @@ static int allreduce_after(Engine& e, int seg)
     switch (seg) {
     case 0: return do_allreduce(e, e.small_stage, e.small_count);   // blocks, gradient and cost at the candidate
     case 1: return do_allreduce(e, e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2);
-    case 2: return do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 1);
+    case 2: return do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 2);   // step | cross term | sync-time-out votes
     default: return VMM_BA_OK;
     }
 }
@@ -643,10 +711,25 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
                     }
                 return VMM_BA_OK;
             });
-            if (rc && e.multi && e.rccl_comm) {
-                // a collective that cannot be recorded: fall back to graphs around eagerly enqueued collectives
-                e.rccl_graph = false;
-                return run_iteration(e, o);
+            if (e.multi && e.rccl_comm) {
+                // Graph or eagerly enqueued collectives is ONE decision for all ranks: a rank that fell back on its own
+                // would enqueue one pass per launch while the others enqueue graph_passes, and the surplus
+                // ncclAllReduce calls of one side would never complete.  So the ranks agree on "everybody captured".
+                bool all_ok = false;
+                const std::string why = rc ? g_err : std::string();
+                int arc;
+                if ((arc = rccl_agree(e, rc == VMM_BA_OK, &all_ok)))
+                    return arc;
+                if (!all_ok) {
+                    // a collective that cannot be recorded (here or on another rank): graphs around eagerly
+                    // enqueued collectives, on every rank
+                    drop_graphs(e);
+                    e.rccl_graph = false;
+                    if (getenv("VMM_BA_DEBUG"))
+                        fprintf(stderr, "[vmm_ba debug] rank %d: RCCL not recorded into the iteration graph (%s)\n", e.rank,
+                                rc ? why.c_str() : "another rank could not");
+                    return run_iteration(e, o);
+                }
             }
             if (rc)
                 return rc;
@@ -680,12 +763,43 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
     return VMM_BA_OK;
 }
 
-static void init_ctl(LmCtl& c, const vmm_ba_options& o, int trace_capacity);
+static void init_ctl(Engine& e, LmCtl& c, const vmm_ba_options& o, int trace_capacity);
+
+// The control block (already read back into e.ctl_host) says done == 2: a workgroup of k_chol_dataflow or
+// k_backsolve_chain gave up waiting for another one in the pass that paused.  That is a scheduling event (several
+// processes time-slicing one GPU, a profiler serialising workgroups), not a property of the matrix: the pass is
+// completed here on the launch-per-block-column factorisation and the per-block back-substitution, which wait for
+// nothing inside a launch, and the loop resumes -- the trust-region policy never learns of it.  Every kernel that
+// was enqueued behind the give-up has returned at once (done != 0).  World > 1: all ranks pause in the same pass
+// (the votes ride on the step all-reduce, k_candidate) and make the same collective calls here.
+static int recover_sync_timeout(Engine& e, const vmm_ba_options& o)
+{
+    LmCtl& c = *e.ctl_host;
+    c.num_sync_timeouts++;
+    c.sync_kernels |= c.sync_timeout;
+    c.sync_timeout = 0;
+    c.lin_fail = 0;
+    c.done = 0;
+    if (e.dbg_spin_once)
+        c.spin_limit_df = c.spin_limit_chain = 0;
+    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
+    Range r("vmm_ba sync time-out recovery");
+    int rc;
+    for (int seg = 1; seg < kNumSeg; ++seg) {
+        if (seg == kNumSeg - 1 && !e.multi)
+            break;
+        enqueue_segment(e, o, seg, true);
+        if (e.multi && (rc = allreduce_after(e, seg)))
+            return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return VMM_BA_OK;
+}
 
 // Control block and candidate buffers at the start of an LM loop: iteration zero evaluates "the candidate" = x.
 static int begin_lm_loop(Engine& e, const vmm_ba_options& o, int trace_capacity)
 {
-    init_ctl(*e.ctl_host, o, trace_capacity);
+    init_ctl(e, *e.ctl_host, o, trace_capacity);
     launch_begin_loop(e, *e.ctl_host);   // control block, staged poses -> state, state -> candidate: one launch
     HIP_TRY(hipGetLastError());
     if (e.dirty_cam || e.dirty_tag) {
@@ -713,9 +827,11 @@ static int flush_state(Engine& e)
     return VMM_BA_OK;
 }
 
-static void init_ctl(LmCtl& c, const vmm_ba_options& o, int trace_capacity)
+static void init_ctl(Engine& e, LmCtl& c, const vmm_ba_options& o, int trace_capacity)
 {
     memset(&c, 0, sizeof(c));
+    c.spin_limit_df = e.dbg_spin_df;
+    c.spin_limit_chain = e.dbg_spin_chain;
     c.max_num_iterations = o.max_num_iterations;
     c.robustify = o.robustify;
     c.jacobi_scaling = o.jacobi_scaling;
@@ -915,6 +1031,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         e.no_chain = nc && nc[0] == '1';
         const char* nd = getenv("VMM_BA_NO_DATAFLOW");
         e.no_dataflow = nd && nd[0] == '1';
+        read_spin_debug_env(e);
     }
     e.K.fx = p->intr[0]; e.K.fy = p->intr[1]; e.K.cx = p->intr[2]; e.K.cy = p->intr[3];
     e.K.k1 = p->dist[0]; e.K.k2 = p->dist[1]; e.K.p1 = p->dist[2]; e.K.p2 = p->dist[3]; e.K.k3 = p->dist[4];
@@ -957,8 +1074,72 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     // observation orders
     const int32_t* own_e = e.elim_cams ? p->obs_cam : p->obs_tag;
     const int32_t* own_f = e.elim_cams ? p->obs_tag : p->obs_cam;
-    if ((rc = build_order(e, e.ordE, e.n_e, own_e, own_f, p->obs_px, p->n_obs))) return fail(rc);
-    if ((rc = build_order(e, e.ordF, e.n_f, own_f, own_e, p->obs_px, p->n_obs))) return fail(rc);
+    std::vector<int32_t> callerE, callerF, startE, startF, otherE;
+    if ((rc = build_order(e, e.ordE, e.n_e, own_e, own_f, p->obs_px, p->n_obs, &callerE, &startE, &otherE))) return fail(rc);
+    if ((rc = build_order(e, e.ordF, e.n_f, own_f, own_e, p->obs_px, p->n_obs, &callerF, &startF))) return fail(rc);
+
+    // Fused evaluation (one evaluation per observation, lane = kept pose): worth it when most (e, f) pairs exist --
+    // a lane whose pair is not observed idles.  VMM_BA_EVAL=fused|twopass overrides.
+    {
+        int n_act = 0;
+        for (int q = 0; q < e.n_e; ++q)
+            n_act += startE[q + 1] > startE[q];
+        e.fused_eval = n_act > 0 && (double)e.n_obs >= 0.6 * (double)n_act * (double)e.n_f;
+        if (const char* ev = getenv("VMM_BA_EVAL")) {
+            if (!strcmp(ev, "fused"))
+                e.fused_eval = n_act > 0;
+            else if (!strcmp(ev, "twopass"))
+                e.fused_eval = false;
+        }
+        if (e.fused_eval) {
+            e.fused_n_e_act = n_act;
+            e.fused_f_pad = round_up(e.n_f, 64);
+            e.fused_chunks = e.fused_f_pad / 64;
+            // eliminated poses per wave: about one wave per SIMD in flight (1024 SIMDs), at most 16
+            e.fused_group = std::min(16, std::max(1, (int)(((int64_t)n_act * e.fused_chunks + 500) / 1000)));
+            if (const char* gv = getenv("VMM_BA_FUSED_GROUP"))
+                e.fused_group = std::min(64, std::max(1, atoi(gv)));
+            e.fused_groups = (n_act + e.fused_group - 1) / e.fused_group;
+            std::vector<int32_t> pair((size_t)e.n_e * e.fused_f_pad, -1), e_list, part0((size_t)e.n_e, 0),
+                ptask((size_t)e.n_e + 1, 0);
+            int slot = 0;
+            for (int q = 0; q < e.n_e; ++q) {
+                ptask[(size_t)q] = slot;
+                part0[(size_t)q] = slot;
+                if (startE[q + 1] > startE[q]) {
+                    e_list.push_back(q);
+                    slot += e.fused_chunks;
+                }
+                // a pair observed twice keeps its last observation here: such input is not supported by the dense
+                // elimination either (one Z block per pair)
+                for (int32_t d = startE[q]; d < startE[q + 1]; ++d)
+                    pair[(size_t)q * e.fused_f_pad + otherE[(size_t)d]] = d;
+            }
+            ptask[(size_t)e.n_e] = slot;
+            // the lookup table cannot hold two observations of one pair: fall back to the two-pass kernel then
+            int64_t n_in_table = 0;
+            for (const int32_t v : pair)
+                n_in_table += v >= 0;
+            if (n_in_table != e.n_obs) {
+                e.fused_eval = false;
+            } else {
+                if ((rc = dev_alloc(e, &e.pair_obs, pair.size()))) return fail(rc);
+                if ((rc = dev_alloc(e, &e.fused_e_list, e_list.size()))) return fail(rc);
+                if ((rc = dev_alloc(e, &e.fused_e_part0, part0.size()))) return fail(rc);
+                if ((rc = dev_alloc(e, &e.fused_pose_task, ptask.size()))) return fail(rc);
+                if ((rc = dev_alloc(e, &e.fused_partE, (size_t)std::max(slot, 1) * kPart))) return fail(rc);
+                if ((rc = dev_alloc(e, &e.fused_partF, (size_t)e.fused_groups * 28 * e.fused_f_pad))) return fail(rc);
+                if ((rc = upload(e, e.pair_obs, pair))) return fail(rc);
+                if ((rc = upload(e, e.fused_e_list, e_list))) return fail(rc);
+                if ((rc = upload(e, e.fused_e_part0, part0))) return fail(rc);
+                if ((rc = upload(e, e.fused_pose_task, ptask))) return fail(rc);
+                if (hipStreamSynchronize(e.stream) != hipSuccess) {   // host vectors go out of scope
+                    set_error("create: upload of the fused-evaluation tables failed");
+                    return fail(VMM_BA_ERR_HIP);
+                }
+            }
+        }
+    }
 
     // normal-equation blocks
     e.small_count = (size_t)42 * n_pose + 2;
@@ -1013,9 +1194,59 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.k_pad = round_up(e.k_dim, kKT);
     if ((rc = dev_alloc(e, &e.Le, (size_t)36 * e.n_e))) return fail(rc);
     if ((rc = dev_alloc(e, &e.ze, (size_t)6 * e.n_e))) return fail(rc);
-    if ((rc = dev_alloc(e, &e.Z, (size_t)e.k_pad * e.ldz))) return fail(rc);
-    // 128-row blocks covering rows 0..n_pad (the last one holds the rhs row) and columns 0..n_pad-1
-    if ((rc = make_syrk_plan(e, e.syrk, (e.n_pad + kST) / kST, (e.n_pad + kST - 1) / kST, e.k_pad))) return fail(rc);
+    // Reduced-system formation: dense Z + MFMA rank-k update, or compressed Z + the pair-list kernel.  Both are
+    // priced per launch from the block structure (rates measured at 500 x 200: the dense update sustains ~44 TFLOP/s
+    // whatever the fill, k_schur_rows ~9 TFLOP/s of useful 6x6x6 block products); VMM_BA_SCHUR=dense|sparse overrides.
+    {
+        double pairs = 0.0;   // 6x6 block products of the lower triangle: sum over e of deg (deg + 1) / 2
+        for (int q = 0; q < e.n_e; ++q) {
+            const double deg = (double)(startE[q + 1] - startE[q]);
+            pairs += 0.5 * deg * (deg + 1.0);
+        }
+        const double dense_flops = (double)(e.n_pad + 1) * (e.n_pad + 2) * e.k_dim;
+        const double sparse_flops = 432.0 * pairs + 72.0 * (double)e.n_obs;
+        const double dense_us = dense_flops / 44e6 + 12.0, sparse_us = sparse_flops / 9e6 + 4.0;
+        e.sparse_schur = e.n_obs > 0 && sparse_us < dense_us;
+        if (const char* sv = getenv("VMM_BA_SCHUR")) {
+            if (!strcmp(sv, "dense"))
+                e.sparse_schur = false;
+            else if (!strcmp(sv, "sparse"))
+                e.sparse_schur = e.n_obs > 0;
+        }
+        e.schur_flops = e.sparse_schur ? sparse_flops : dense_flops;
+    }
+    if (e.sparse_schur) {
+        if ((rc = dev_alloc(e, &e.Zc, (size_t)36 * std::max<int64_t>(e.n_obs, 1)))) return fail(rc);
+        std::vector<int32_t> posE((size_t)e.n_obs), f2e((size_t)e.n_obs);
+        for (int64_t d = 0; d < e.n_obs; ++d)
+            posE[(size_t)callerE[(size_t)d]] = (int32_t)d;
+        for (int64_t d = 0; d < e.n_obs; ++d)
+            f2e[(size_t)d] = posE[(size_t)callerF[(size_t)d]];
+        if ((rc = dev_alloc(e, &e.f2e, f2e.size()))) return fail(rc);
+        if ((rc = upload(e, e.f2e, f2e))) return fail(rc);
+        // work items of k_schur_rows: (kept pose, column group), the longest rows first; the accumulator of a group
+        // (6 x 6 group_tags doubles) stays under 64 KB of LDS, two workgroups per CU
+        const int max_tags = 220;
+        const int n_grp = (e.n_f + max_tags - 1) / max_tags;
+        e.row_group_tags = (e.n_f + n_grp - 1) / n_grp;
+        std::vector<int32_t> items;
+        for (int f = e.n_f - 1; f >= 0; --f)
+            for (int g = 0; g * e.row_group_tags <= f; ++g) {
+                items.push_back(f);
+                items.push_back(g);
+            }
+        items.push_back(e.n_f);   // the padding rows
+        items.push_back(0);
+        e.n_row_items = (int)(items.size() / 2);
+        if ((rc = dev_alloc(e, &e.row_items, items.size()))) return fail(rc);
+        if ((rc = upload(e, e.row_items, items))) return fail(rc);
+        if (hipStreamSynchronize(e.stream) != hipSuccess) {   // host vectors go out of scope
+            set_error("create: upload of the block-sparse plan failed");
+            return fail(VMM_BA_ERR_HIP);
+        }
+    } else {
+        if ((rc = ensure_dense_schur(e))) return fail(rc);
+    }
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
     if (e.multi && (rc = dev_alloc(e, &e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2))) return fail(rc);
     if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * e.ldz))) return fail(rc);
@@ -1072,6 +1303,8 @@ int vmm_ba_set_allreduce(vmm_ba_handle h, vmm_ba_allreduce_fn fn, void* user)
     e.allreduce_user = user;
     return VMM_BA_OK;
 }
+
+int vmm_ba_rccl_available(void) { return rccl().ok ? 1 : 0; }
 
 int vmm_ba_rccl_unique_id(void* id128)
 {
@@ -1269,6 +1502,17 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
         }
         HIP_TRY(hipMemcpyAsync(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream));
         HIP_TRY(hipStreamSynchronize(e.stream));
+        if (e.ctl_host->done == 2) {
+            // a spin give-up, not a numerical failure: finish that pass on the fallback path and go on
+            if (e.ctl_host->num_sync_timeouts >= 1000) {
+                set_error("the one-launch factorisation gave up waiting in 1000 passes of one solve (kernels: "
+                          + std::to_string(e.ctl_host->sync_kernels | e.ctl_host->sync_timeout) + ")");
+                return VMM_BA_ERR_HIP;
+            }
+            if ((rc = recover_sync_timeout(e, o))) return rc;
+            enq = e.ctl_host->num_lm_iterations;   // the passes enqueued behind the paused one did nothing
+            continue;
+        }
         if (e.ctl_host->done)
             break;
         if (enq >= max_steps) {
@@ -1292,6 +1536,9 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
     s->time_eliminate_s = 1e-8 * (double)c.phase_ticks[2];
     s->time_factor_solve_s = 1e-8 * (double)c.phase_ticks[3];
     s->time_step_s = 1e-8 * (double)c.phase_ticks[4];
+    s->num_sync_timeouts = c.num_sync_timeouts;
+    s->sync_timeout_kernels = c.sync_kernels;
+    s->block_sparse = e.sparse_schur ? 1 : 0;
     if (user_trace && user_cap > 0) {
         const int n = std::min(c.records, user_cap);
         if (n > 0) {
@@ -1422,15 +1669,18 @@ int vmm_ba_tag_translation_covariance(vmm_ba_handle h, int robustify, double hub
     vmm_ba_default_options(&o);
     o.robustify = robustify;
     o.huber_a = huber_a;
-    init_ctl(*e.ctl_host, o, 0);
-    HIP_TRY(hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream));
-    // the iteration's kernels on the undamped, unscaled system: H blocks, Z, S = L L^T (+ block inverses)
-    launch_eval_passes(e, robustify, huber_a, false);
-    launch_cov_prepare(e);
-    launch_elim(e);
-    launch_syrk_reduced(e);
-    launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
-    launch_chol_inverse(e, e.n_blk - 1);
+    // the covariance kernels read Z as a dense matrix: a handle on the block-sparse path switches over for this call
+    const bool was_sparse = e.sparse_schur;
+    if (was_sparse) {
+        int drc;
+        if ((drc = ensure_dense_schur(e))) return drc;
+        e.sparse_schur = false;
+    }
+    struct Restore {
+        Engine& e;
+        bool v;
+        ~Restore() { e.sparse_schur = v; }
+    } restore_path{ e, was_sparse };
     // L X = B with B = I (tags kept) or Z^T (tags eliminated), then per-tag Gram blocks
     const bool identity_rhs = e.elim_cams;
     const int n_rhs = identity_rhs ? e.n_pad : e.k_dim;
@@ -1438,19 +1688,35 @@ int vmm_ba_tag_translation_covariance(vmm_ba_handle h, int robustify, double hub
     double *B = nullptr, *cov_dev = nullptr;
     hipError_t err = hipMalloc((void**)&B, sizeof(double) * (size_t)e.n_pad * ldb);
     if (err == hipSuccess) err = hipMalloc((void**)&cov_dev, sizeof(double) * 9 * (size_t)e.n_tags);
-    if (err == hipSuccess) err = hipMemsetAsync(B, 0, sizeof(double) * (size_t)e.n_pad * ldb, e.stream);
-    if (err == hipSuccess) {
-        launch_cov_rhs(e, B, ldb, identity_rhs);
-        launch_cov_trsm(e, B, ldb, ldb / 64, identity_rhs);
-        launch_cov_gram(e, B, ldb, cov_dev);
-        err = hipGetLastError();
+    // second attempt only after a spin give-up of the one-launch factorisation: the same on the fallback path
+    for (int attempt = 0; attempt < 2 && err == hipSuccess; ++attempt) {
+        init_ctl(e, *e.ctl_host, o, 0);
+        err = hipMemcpyAsync(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream);
+        if (err != hipSuccess)
+            break;
+        // the iteration's kernels on the undamped, unscaled system: H blocks, Z, S = L L^T (+ block inverses)
+        launch_eval_passes(e, robustify, huber_a, false);
+        launch_cov_prepare(e);
+        launch_elim(e);
+        launch_syrk_reduced(e);
+        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl, attempt > 0);
+        launch_chol_inverse(e, e.n_blk - 1);
+        err = hipMemsetAsync(B, 0, sizeof(double) * (size_t)e.n_pad * ldb, e.stream);
+        if (err == hipSuccess) {
+            launch_cov_rhs(e, B, ldb, identity_rhs);
+            launch_cov_trsm(e, B, ldb, ldb / 64, identity_rhs);
+            launch_cov_gram(e, B, ldb, cov_dev);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(cov, cov_dev, sizeof(double) * 9 * (size_t)e.n_tags, hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess)
+            err = hipStreamSynchronize(e.stream);
+        if (err != hipSuccess || e.ctl_host->done != 2)
+            break;
     }
-    if (err == hipSuccess)
-        err = hipMemcpyAsync(cov, cov_dev, sizeof(double) * 9 * (size_t)e.n_tags, hipMemcpyDeviceToHost, e.stream);
-    if (err == hipSuccess)
-        err = hipMemcpyAsync(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream);
-    if (err == hipSuccess)
-        err = hipStreamSynchronize(e.stream);
     (void)hipFree(B);
     (void)hipFree(cov_dev);
     if (err != hipSuccess) {
@@ -1594,6 +1860,7 @@ static int make_scratch(Engine& e, int device, int ld)
     if ((rc = dev_alloc(e, &e.gran, (size_t)2 * ld))) return rc;
     { const char* nc = getenv("VMM_BA_NO_CHAIN"); e.no_chain = nc && nc[0] == '1'; }
     { const char* nd = getenv("VMM_BA_NO_DATAFLOW"); e.no_dataflow = nd && nd[0] == '1'; }
+    read_spin_debug_env(e);
     {
         const int nb = ld / kNB - 1;   // ld = n_pad + 64
         if (!e.no_dataflow && dataflow_workgroups(nb) <= e.n_cu
@@ -1640,16 +1907,28 @@ int vmm_ba_dense_spd_solve(int device, int n, const double* A, const double* b, 
         hs[(size_t)i * ld + i] = 1.0;
     for (int j = 0; j < n; ++j)
         hs[(size_t)n_pad * ld + j] = b[j];
-    hipError_t err = hipMemcpyAsync(S, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, e.stream);
-    if (err == hipSuccess) {
-        launch_cholesky_solve(e, S, n_pad, ld, y, e.ctl);
-        err = hipGetLastError();
-    }
     LmCtl c;
-    memset(&c, 0, sizeof(c));
-    if (err == hipSuccess) err = hipMemcpyAsync(x, y, sizeof(double) * n, hipMemcpyDeviceToHost, e.stream);
-    if (err == hipSuccess) err = hipMemcpyAsync(&c, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream);
-    if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
+    hipError_t err = hipSuccess;
+    // second attempt only after a spin give-up of the one-launch kernels: the same system on the fallback path
+    for (int attempt = 0; attempt < 2 && err == hipSuccess; ++attempt) {
+        memset(&c, 0, sizeof(c));
+        if (attempt == 0) {
+            c.spin_limit_df = e.dbg_spin_df;
+            c.spin_limit_chain = e.dbg_spin_chain;
+        }
+        err = hipMemcpyAsync(e.ctl, &c, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(S, hs.data(), sizeof(double) * hs.size(), hipMemcpyHostToDevice, e.stream);
+        if (err == hipSuccess) {
+            launch_cholesky_solve(e, S, n_pad, ld, y, e.ctl, attempt > 0);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipMemcpyAsync(x, y, sizeof(double) * n, hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess) err = hipMemcpyAsync(&c, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost, e.stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(e.stream);
+        if (c.done != 2)
+            break;
+    }
     free_scratch(e);
     if (err != hipSuccess) {
         set_error(std::string("dense_spd_solve: ") + hipGetErrorString(err));
@@ -1729,10 +2008,23 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     out->n_obs = e.n_obs;
     out->reduced_dim = e.n_red;
     out->elim_dim = e.k_dim;
-    // keep the caller's state: timing runs real iterations
+    out->schur_sparse = e.sparse_schur ? 1 : 0;
+    out->schur_flops = e.schur_flops;
+    // keep the caller's state: timing runs real iterations.  The RAW device buffers are saved and restored: through
+    // vmm_ba_get_state / vmm_ba_set_state a point-landmark handle would get its tags back as exact rectangles rebuilt
+    // from re-orthogonalised poses, not the optimised free corners it held.
     std::vector<double> cam0((size_t)7 * e.n_cams), tag0((size_t)7 * e.n_tags);
     int rc;
-    if ((rc = vmm_ba_get_state(h, cam0.data(), tag0.data()))) return rc;
+    HIP_TRY(hipMemcpyAsync(cam0.data(), e.cam_qt, sizeof(double) * cam0.size(), hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipMemcpyAsync(tag0.data(), e.tag_qt, sizeof(double) * tag0.size(), hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    auto restore_raw = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(e.cam_qt, cam0.data(), sizeof(double) * cam0.size(), hipMemcpyHostToDevice, e.stream));
+        HIP_TRY(hipMemcpyAsync(e.tag_qt, tag0.data(), sizeof(double) * tag0.size(), hipMemcpyHostToDevice, e.stream));
+        HIP_TRY(hipStreamSynchronize(e.stream));
+        e.dirty_cam = e.dirty_tag = false;
+        return VMM_BA_OK;
+    };
     if (e.trace_capacity < 1) {
         if ((rc = dev_alloc(e, &e.trace, 1, false))) return rc;
         e.trace_capacity = 1;
@@ -1748,8 +2040,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     HIP_TRY(hipStreamSynchronize(e.stream));
     // the priming step was accepted and moved x; go back so that the W recomputed by the timed
     // evaluation passes stays consistent with the H blocks of the priming evaluation
-    if ((rc = vmm_ba_set_state(h, cam0.data(), tag0.data()))) return rc;
-    if ((rc = flush_state(e))) return rc;   // the timed pieces read the poses on the device
+    if ((rc = restore_raw())) return rc;   // the timed pieces read the poses on the device
     hipEvent_t ev0, ev1;
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
@@ -1807,7 +2098,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
                 e.ctl_host->done, e.ctl_host->lin_fail, e.ctl_host->termination, e.ctl_host->iteration);
     }
     // whole iterations from the caller's state
-    if ((rc = vmm_ba_set_state(h, cam0.data(), tag0.data()))) return rc;
+    if ((rc = restore_raw())) return rc;
     if ((rc = begin_lm_loop(e, ot, 0))) return rc;
     HIP_TRY(hipEventRecord(ev0, e.stream));
     int passes = 0;
@@ -1822,7 +2113,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     out->lm_iteration_ms = ms / passes;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
-    return vmm_ba_set_state(h, cam0.data(), tag0.data());
+    return restore_raw();
 }
 
 } // extern "C"

@@ -93,6 +93,15 @@ def enable_native_rccl(ba, rank, group=None):
         except Exception as exc:   # noqa: BLE001 -- carried to every rank so that all of them raise together
             payload[0] = "rank 0 could not draw an RCCL id: %s" % exc
     dist.broadcast_object_list(payload, src=0, group=group)
-    if not isinstance(payload[0], (bytes, bytearray)):
-        raise RuntimeError(str(payload[0]))
+    # Every rank says whether it can enter ncclCommInitRank (library resolved, id received) and the ranks agree on
+    # the minimum over the launcher's process group BEFORE anyone calls vmm_ba_enable_rccl: a rank that raised here on
+    # its own would leave the others blocked inside ncclCommInitRank waiting for it.
+    mine_ok = isinstance(payload[0], (bytes, bytearray)) and eng.rccl_available()
+    ready = torch.tensor([1 if mine_ok else 0], dtype=torch.int32,
+                         device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(ready, op=dist.ReduceOp.MIN, group=group)
+    if int(ready.item()) != 1:
+        if not isinstance(payload[0], (bytes, bytearray)):
+            raise RuntimeError(str(payload[0]))
+        raise RuntimeError("librccl.so is not loadable on %s" % ("this rank" if not mine_ok else "another rank"))
     ba.enable_rccl(payload[0])

@@ -136,7 +136,7 @@ class BundleAdjuster:
             s.trace, s.trace_capacity = buf, trace_capacity
         _lib.check(_lib.lib().vmm_ba_solve(self._h, C.byref(o), C.byref(s)))
         out = {k: getattr(s, k) for k, _ in _lib.Summary._fields_
-               if k not in ("trace", "trace_capacity", "reserved")}
+               if k not in ("trace", "trace_capacity", "reserved", "reserved2")}
         trace = []
         if buf is not None:
             for i in range(min(s.iterations, trace_capacity)):
@@ -181,6 +181,11 @@ class BundleAdjuster:
         t = _lib.KernelTimes()
         _lib.check(_lib.lib().vmm_ba_time_kernels(self._h, C.byref(o), int(reps), C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.KernelTimes._fields_}
+
+
+def rccl_available():
+    """True when librccl.so was resolved in this process (vmm_ba_rccl_available; no device call)."""
+    return bool(_lib.lib().vmm_ba_rccl_available())
 
 
 def rccl_unique_id():
