@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=14)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs index (1-based)")
     ap.add_argument("--visibility", type=float, default=1.0)
+    ap.add_argument("--neighbors", type=int, nargs=2, default=None, metavar=("MIN", "MAX"),
+                    help="close-up scene: every image sees the MIN..MAX tags nearest to the wall point it looks at")
     ap.add_argument("--poll", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", choices=["rccl", "callback"], default="rccl",
@@ -142,6 +144,8 @@ def main():
     overrides = {}
     if a.visibility < 1.0:
         overrides["visibility"] = a.visibility
+    if a.neighbors:
+        overrides["neighbors_min"], overrides["neighbors_max"] = a.neighbors
     s = make_scene(a.config, **overrides)
     n_cams, n_tags = len(s.cam_init), len(s.tag_init)
     elim = {"auto": eng.ELIM_AUTO, "cams": eng.ELIM_CAMERAS, "tags": eng.ELIM_TAGS}[a.elimination]

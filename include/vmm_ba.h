@@ -298,6 +298,11 @@ int vmm_ba_dense_syrk(int device, int k, int n, const double* Z, double* C);
  * (src/TagReconstructor.cpp:665-666,692-693 attach it to every q block; tangent order: translation, rotation). */
 int vmm_ba_pose_plus(int64_t n, const double* qt, const double* delta, double* out, int device);
 
+/* Diagnostic (can the reduced-system assembly hide behind the factorisation?): ms[0] rank-k update + sum
+ * alone, ms[1] factorisation + triangular solves alone, ms[2] both back to back on one stream, ms[3] both at once on
+ * two streams (no data dependency between them in this measurement).  Dense elimination, one GPU. */
+int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms);
+
 /* Times each kernel of an LM iteration at the current state (reps launches each). */
 int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vmm_ba_kernel_times* out);
 

@@ -175,16 +175,22 @@ struct Engine {
     // S -= Z^T Z runs over pairs that share an eliminated pose.  Chosen at create by a cost model (VMM_BA_SCHUR=
     // dense|sparse overrides): at full visibility the dense MFMA rank-k update is the faster one.
     bool sparse_schur = false;
-    double* Zc = nullptr;           // [36 * n_obs]: per eliminated pose a 6 x 6 deg(e) row-major panel at 36 * start[e]
+    double* Zc = nullptr;           // [n_obs][36]: one row-major 6x6 block per observation, E order
     int32_t* f2e = nullptr;         // [n_obs] F-order position -> E-order position of the same observation
-    int32_t* row_items = nullptr;   // [2 * n_row_items] (kept pose, column group) work items of k_schur_rows
-    int n_row_items = 0, row_group_tags = 0;
+    // the symbolic structure of S -= Z^T Z (built once at create): pairs of kept poses (row f: f' = 0..f, then the rhs),
+    // the terms of every pair, and the work items of k_schur_pairs (row | first pair; up to 42 pairs of one row each)
+    int32_t* pair_start = nullptr;  // [n_f + 1]
+    int32_t* pair_tstart = nullptr; // [n_pairs + 1]
+    int32_t* pair_terms = nullptr;  // [n_terms][2] position of the left block in the row's observation list | E-order
+                                    // index of the right block (rhs pair: the eliminated pose)
+    int32_t* row_items = nullptr;   // [2][n_row_items]
+    int n_row_items = 0;
     double schur_flops = 0.0;       // algorithmic flops of the reduced-system formation on the path in use
     SyrkPlan syrk;                  // stream-K plan of S = Z^T Z
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
     double* S_packed = nullptr;     // world > 1: rows 0..n_pad of the lower triangle, packed, for the all-reduce
-    double* P = nullptr;            // [2][kNB][ldz] transposed Cholesky panels (alternating)
-    double* P2[2] = { nullptr, nullptr };
+    double* P = nullptr;            // [3][kNB][ldz] transposed Cholesky panels (rotating: the trailing updates apply two at a time)
+    double* P2[3] = { nullptr, nullptr, nullptr };
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
     double* Ldiag = nullptr;        // [n_blk][64][64] Cholesky factors of the diagonal blocks
     double* Linv = nullptr;         // [n_blk][64][64] their inverses (all but the last block)

@@ -264,11 +264,49 @@ void k_eval_fused(const EvalArgs a, const FusedArgs fa)
     for (int k = 0; k < 6; ++k)
         gF[k] = 0.0;
     const int e0 = grp * fa.group, e1 = min(e0 + fa.group, fa.n_e_act);
+    // One wave per SIMD (the accumulators of both families need ~330 registers), so nothing else hides the memory
+    // latency: the loads of an observation are issued one eliminated pose ahead of their use (pixels, mask) and its
+    // lookup two poses ahead.
+    constexpr int NPX = POINTS ? 4 : 8;
+    int e_n = __builtin_amdgcn_readfirstlane(fa.e_list[e0]);
+    int idx_n = fvalid ? fa.pair_obs[(int64_t)e_n * fa.n_f_pad + f] : -1;
+    int e_nn = e_n, idx_nn = -1;
+    if (e0 + 1 < e1) {
+        e_nn = __builtin_amdgcn_readfirstlane(fa.e_list[e0 + 1]);
+        idx_nn = fvalid ? fa.pair_obs[(int64_t)e_nn * fa.n_f_pad + f] : -1;
+    }
+    double px_n[NPX];
+    int on_n;
+    {
+        const int64_t isn = idx_n >= 0 ? idx_n : 0;
+#pragma unroll
+        for (int k = 0; k < NPX; ++k)
+            px_n[k] = a.px[(int64_t)k * a.n_pad + isn];
+        on_n = idx_n >= 0 && a.mask[a.caller[isn]];
+    }
     for (int ei = e0; ei < e1; ++ei) {
-        const int e = __builtin_amdgcn_readfirstlane(fa.e_list[ei]);
-        const int idx = fvalid ? fa.pair_obs[(int64_t)e * fa.n_f_pad + f] : -1;
+        const int e = e_n;
+        const int idx = idx_n;
         const bool valid = idx >= 0;
-        const int64_t is = valid ? idx : 0;
+        const bool on = on_n != 0;
+        double pxc[NPX];
+#pragma unroll
+        for (int k = 0; k < NPX; ++k)
+            pxc[k] = px_n[k];
+        // prefetch: the next pose's observation, the lookup of the one after it
+        e_n = e_nn;
+        idx_n = idx_nn;
+        if (ei + 1 < e1) {
+            const int64_t isn = idx_n >= 0 ? idx_n : 0;
+#pragma unroll
+            for (int k = 0; k < NPX; ++k)
+                px_n[k] = a.px[(int64_t)k * a.n_pad + isn];
+            on_n = idx_n >= 0 && a.mask[a.caller[isn]];
+        }
+        if (ei + 2 < e1) {
+            e_nn = __builtin_amdgcn_readfirstlane(fa.e_list[ei + 2]);
+            idx_nn = fvalid ? fa.pair_obs[(int64_t)e_nn * fa.n_f_pad + f] : -1;
+        }
         const int tag_idx = E_IS_CAM ? fs : e;
         const double* elimq = a.own_pose + 7 * (int64_t)e;   // wave-uniform
         Rigid elim;
@@ -286,7 +324,6 @@ void k_eval_fused(const EvalArgs a, const FusedArgs fa)
         const double* camq = E_IS_CAM ? elimq : keptq;
         const double hw = POINTS ? 0.0 : 0.5 * a.tag_wh[2 * tag_idx], hh = POINTS ? 0.0 : 0.5 * a.tag_wh[2 * tag_idx + 1];
         const double tag_on = ((tag_idx >> a.fixed_shift) == a.fixed_tag) ? 0.0 : 1.0;
-        const bool on = valid && a.mask[a.caller[is]];
         AT H[21];
         double g[6], cost = 0.0;
         AT Wacc[36];
@@ -299,12 +336,18 @@ void k_eval_fused(const EvalArgs a, const FusedArgs fa)
 #pragma unroll
         for (int k = 0; k < 36; ++k)
             Wacc[k] = (AT)0;
+        // not unrolled (four copies of the corner's temporaries spill even at one wave per SIMD); the corner's pixels
+        // are selected from the prefetched registers, never indexed (a runtime-indexed register array lives in scratch)
 #pragma unroll 1
         for (int cn = 0; cn < (POINTS ? 2 : 4); ++cn) {
             const double sx = (cn == 1 || cn == 2) ? hw : -hw;
             const double sy = (cn >= 2) ? hh : -hh;
-            const double u = a.px[(2 * cn) * a.n_pad + is];
-            const double v = a.px[(2 * cn + 1) * a.n_pad + is];
+            double u = pxc[0], v = pxc[1];
+#pragma unroll
+            for (int k = 1; k < NPX / 2; ++k) {
+                u = (cn == k) ? pxc[2 * k] : u;
+                v = (cn == k) ? pxc[2 * k + 1] : v;
+            }
             CornerEval ce;
             if (POINTS) {
                 eval_point<true, true>(a.K, cam, camq, pt[3 * cn], pt[3 * cn + 1], pt[3 * cn + 2], u, v, ce, on);

@@ -475,8 +475,8 @@ __device__ __forceinline__ void candidate_for_pose(const PoseViews& pv, const in
 // One wave per eliminated pose.
 // FUSE (one GPU): the candidate of every pose is formed here too -- an eliminated pose's by lane 0 of its wave, the
 // kept poses' by one thread each in the workgroups behind the eliminated family's -- instead of in k_candidate.
-// SPARSE: Z is the compressed Engine::Zc (a 6 x 6 deg(e) panel per eliminated pose); the product with y_f gathers
-// the kept poses of e's observations.
+// SPARSE: Z is the compressed Engine::Zc (one 6x6 block per observation, E order); the product with y_f gathers the
+// kept poses of e's observations.
 template <bool FUSE, bool SPARSE>
 __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose,
                                                  const int32_t* __restrict__ pose_task,
@@ -539,13 +539,13 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
     double acc[6] = { 0, 0, 0, 0, 0, 0 };
     if (SPARSE) {
         const int es = e_start[e], rs = 6 * (e_start[e + 1] - es);
-        const double* zp = Z + 36 * (int64_t)es;
+        const double* zp = Z + 36 * (int64_t)es;   // the pose's blocks: [observation][6][6]
         for (int t = (int)threadIdx.x; t < rs; t += 256) {
             const int k = t / 6, c = t - 6 * k;
             const double yv = yf[6 * (int64_t)e_other[es + k] + c];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                acc[i] += zp[i * rs + t] * yv;
+                acc[i] += zp[36 * k + 6 * i + c] * yv;
         }
     } else {
         const double* zr = Z + (int64_t)(6 * e) * ldz;

@@ -51,8 +51,8 @@ __device__ __forceinline__ bool chol6(double* A)
 // observation stores L_e, z_e and the rhs column of Z.  A pose without observations owns no thread: nobody reads
 // its L_e, and its rows of Z (zero since vmm_ba_create) stay zero -- also what a rank needs for a pose whose
 // observations live on another rank.
-// SPARSE: the block goes into the compressed Z (Engine::Zc: per eliminated pose a 6 x 6 deg(e) row-major panel at
-// 36 * start[e], the pose's observations in E order) instead of into the dense matrix, and the rhs lives in ze only.
+// SPARSE: the block goes into the compressed Z (Engine::Zc: one row-major 6x6 block per observation, E order)
+// instead of into the dense matrix, and the rhs lives in ze only.
 template <typename WT, bool SPARSE>
 __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64_t n_pad,
                                                  const int32_t* __restrict__ own,
@@ -138,9 +138,8 @@ __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64
     int64_t rs = ldz;
     double* zrow = Z + (int64_t)(6 * e) * ldz + 6 * f;
     if (SPARSE) {
-        const int es = e_start[e];
-        rs = 6 * (int64_t)(e_start[e + 1] - es);
-        zrow = Z + 36 * (int64_t)es + 6 * (i - es);
+        rs = 6;
+        zrow = Z + 36 * i;
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -391,148 +390,178 @@ __global__ void k_add_diag(const LmCtl* ctl, int n_f, int f_off_pose, const doub
 // ---- block-sparse reduced system: S(f, f') -= sum over the eliminated poses e that see both f and f' --------------
 //
 // The dense path stores Z with its zero blocks and multiplies them (at 25 % visibility 15/16 of the rank-k flops);
-// here Z holds only the blocks of co-observed pairs (Engine::Zc) and the product runs over pairs that share an e --
-// what the sparse normal-Cholesky behind ceres::Solve (src/TagReconstructor.cpp:725-738) exploits on projects where an
-// image sees a handful of tags (README.md:155-216).  No atomics, fixed summation order:
-//   * one workgroup per (kept pose f, column group): its LDS holds the 6 rows of S that belong to f for the group's
-//     columns (f' <= f: lower triangle), accumulated over the poses e that see f, in the order of f's observations;
-//   * for one e the 36 entries of Z_ef are wave-uniform (scalar registers), a lane owns one column (f', c) of e's
-//     panel: six loads, 36 multiply-adds, six read-modify-writes of the LDS accumulator;
-//   * column f' belongs to wave f' & 3 of the workgroup for the whole kernel, so no two waves ever touch the same
-//     accumulator entry and every entry is summed in e order: bit-repeatable.  A wave finds its columns of e with one
-//     ballot over e's neighbour list (any order, any length).
-// The group's rows are written once, with the kept family's damped diagonal block and right-hand side (one GPU), and
-// with zeros up to the next 64-column boundary: the Cholesky kernels load whole 16x16 tiles of the diagonal blocks.
-struct RowArgs {
+// here Z holds only the blocks of co-observed pairs (Engine::Zc, one row-major 6x6 block per observation, E order)
+// and the product runs over pairs of observations that share an eliminated pose -- what the sparse normal-Cholesky
+// behind ceres::Solve (src/TagReconstructor.cpp:725-738) exploits on projects where an image sees a handful of tags
+// (README.md:155-216).  The structure is symbolic work done once at vmm_ba_create: for every pair of kept poses
+// (f, f' <= f) the list of its terms (position of observation (e, f) in f's row, E-order index of (e, f')), in e order.
+//   * a lane owns one output column (f, f', c): six accumulators in registers, summed over the pair's terms in list
+//     order -- no atomics, no shared accumulator, one writer per element: bit-repeatable;
+//   * a workgroup takes up to 42 consecutive pairs of ONE row f, so the left operands Z_ef (the row's blocks, 288 B
+//     each) are staged once in LDS (128 at a time) and read from there; the right operand is six doubles per term;
+//   * every pair of the lower triangle is written, the empty ones as zeros, together with the kept family's damped
+//     diagonal block; each row's last pair is its right-hand side entry b_f = s_f g_f - sum_e Z_ef^T z_e.
+struct PairArgs {
     const LmCtl* ctl;
-    const int32_t* items;       // [n_items][2]: kept pose (n_f = the padding rows), column group
-    int group_tags;             // tags per column group (accumulator: 6 x 6 group_tags doubles)
-    int n_f;
+    const int32_t* item_row;    // [n_items] kept pose of the item
+    const int32_t* item_p0;     // [n_items] first pair (global pair id); the item ends at min(p0 + 42, end of the row)
+    const int32_t* pair_start;  // [n_f + 1] first pair id of every row; row f has the pairs f' = 0..f and the rhs
+    const int32_t* tstart;      // [n_pairs + 1] term range of every pair
+    const int2* terms;          // [n_terms] .x: position of the left block in the row's observation list, .y: E-order
+                                // observation index of the right block (rhs pair: the eliminated pose)
     const int32_t* f_start;     // [n_f + 1] F-order observation range of every kept pose
-    const int32_t* f_other;     // [n_obs]  F order: the eliminated pose
-    const int32_t* f2e;         // [n_obs]  F order -> E-order position
-    const int32_t* e_start;     // [n_e + 1]
-    const int32_t* e_other;     // [n_obs]  E order: the kept pose
-    const double* Zc;
-    const double* ze;
+    const int32_t* f2e;         // [n_obs] F order -> E-order index
+    const double* Zc;           // [n_obs][36]
+    const double* ze;           // [n_e][6]
     double* S;
-    int ld;
+    int ld, n_items, n_f;
     DiagArgs da;
     int add_diag;
 };
 
-__global__ __launch_bounds__(256, 2) void k_schur_rows(RowArgs a)
+constexpr int kPairChunk = 128;   // left blocks staged per pass: 36 KB of LDS, four workgroups per CU
+constexpr int kPairsPerItem = 42; // 6 lanes per pair: 252 of 256 threads
+
+__global__ __launch_bounds__(256) void k_schur_pairs(PairArgs a)
 {
     if (a.ctl && a.ctl->done)
         return;
-    extern __shared__ __attribute__((aligned(16))) double rows_smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int f = a.items[2 * blockIdx.x], g = a.items[2 * blockIdx.x + 1];
+    const int tid = threadIdx.x;
     const int n_red = a.da.n_red, n_pad = a.da.n_pad, ld = a.ld;
-    if (f >= a.n_f) {
-        // padding of the reduced system: rows n_red .. n_pad-1 = unit rows (one GPU; world > 1: zero, k_add_diag sets
-        // the ones behind the all-reduce), and the right-hand side's padding entries
-        for (int i = n_red + (tid >> 6); i < n_pad; i += 4)
-            for (int j = lane; j < n_pad; j += 64)
-                a.S[(int64_t)i * ld + j] = (a.add_diag && i == j) ? 1.0 : 0.0;
-        for (int j = n_red + tid; j < n_pad; j += 256)
-            a.S[(int64_t)n_pad * ld + j] = 0.0;
+    if ((int)blockIdx.x >= a.n_items) {
+        // what no pair writes: the rest of every row's diagonal 64-block (the Cholesky kernels load whole 16x16 tiles
+        // of it) and the padding of the reduced system (unit rows on one GPU; world > 1: zero, k_add_diag sets the ones
+        // behind the all-reduce)
+        const int nb = gridDim.x - a.n_items, b = (int)blockIdx.x - a.n_items;
+        for (int row = b; row <= n_pad; row += nb) {
+            if (row == n_pad) {
+                for (int j = n_red + tid; j < n_pad; j += 256)
+                    a.S[(int64_t)n_pad * ld + j] = 0.0;
+            } else if (row >= n_red) {
+                for (int j = tid; j < n_pad; j += 256)
+                    a.S[(int64_t)row * ld + j] = (a.add_diag && j == row) ? 1.0 : 0.0;
+            } else {
+                const int c0 = 6 * (row / 6) + 6, c1 = min((row / 64) * 64 + 64, n_pad);
+                for (int j = c0 + tid; j < c1; j += 256)
+                    a.S[(int64_t)row * ld + j] = 0.0;
+            }
+        }
         return;
     }
-    const int lo = g * a.group_tags;
-    const int hi = min(lo + a.group_tags, f + 1);   // columns f' in [lo, hi): the lower triangle ends at f
-    const int W = 6 * a.group_tags;
-    double* acc = rows_smem;                                             // [6][W]
-    int* slist = reinterpret_cast<int*>(rows_smem + 6 * W) + w * 128;    // this wave's [64] slots | [64] columns
-    for (int i = tid; i < 6 * W; i += 256)
-        acc[i] = 0.0;
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) double As[kPairChunk * 36];
+    const int f = a.item_row[blockIdx.x];
+    const int row_p0 = a.pair_start[f];
+    const int p = a.item_p0[blockIdx.x] + tid / 6, c = tid % 6;
+    const int j = p - row_p0;                      // f' (0..f) or f + 1: the right-hand side
+    const bool valid = tid < 6 * kPairsPerItem && j <= f + 1;
+    const bool rhs = j == f + 1;
+    int t = valid ? a.tstart[p] : 0;
+    const int t1 = valid ? a.tstart[p + 1] : 0;
+    const int fs = a.f_start[f], len = a.f_start[f + 1] - fs;
     const double* __restrict__ Zc = a.Zc;
-    double bacc = 0.0;   // wave 0, lanes 0..5 of group 0: (Z^T z)_f
-    const int i0 = a.f_start[f], i1 = a.f_start[f + 1];
-    for (int idx = i0; idx < i1; ++idx) {
-        const int e = __builtin_amdgcn_readfirstlane(a.f_other[idx]);
-        const int ie = __builtin_amdgcn_readfirstlane(a.f2e[idx]);
-        const int es = __builtin_amdgcn_readfirstlane(a.e_start[e]);
-        const int deg = __builtin_amdgcn_readfirstlane(a.e_start[e + 1]) - es;
-        const int rs = 6 * deg;
-        const double* __restrict__ P = Zc + 36 * (int64_t)es;      // e's panel: 6 rows of 6 deg doubles
-        const double* __restrict__ Pf = P + 6 * (ie - es);         // Z_ef: wave-uniform
-        double A[6][6];
+    double acc[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    const bool active = valid && (!rhs || c == 0);
+    const int2* __restrict__ terms = a.terms;
+    for (int lo = 0; lo < len; lo += kPairChunk) {
+        const int hi = min(lo + kPairChunk, len);
+        if (lo > 0)
+            __syncthreads();   // the previous pass's blocks are no longer read
+        // stage the row's blocks lo .. hi-1: thread -> (block, pair of doubles).  All indices first, then all blocks:
+        // two memory latencies per pass, not two per block.
+        {
+            constexpr int NI = kPairChunk * 18 / 256;
+            int ie[NI];
+            double2 v[NI];
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-                A[r][q] = Pf[r * rs + q];
-        if (g == 0 && w == 0 && lane < 6) {
-            double t = 0.0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-                t += Pf[r * rs + lane] * a.ze[6 * (int64_t)e + r];
-            bacc += t;
-        }
-        for (int base = 0; base < deg; base += 64) {
-            const int slot = base + lane;
-            const int fp = slot < deg ? a.e_other[es + slot] : -1;
-            const bool own = fp >= lo && fp < hi && (fp & 3) == w;
-            const unsigned long long mask = __ballot(own);
-            const int cnt = __popcll(mask);
-            if (cnt == 0)
-                continue;
-            if (own) {
-                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-                slist[rank] = slot;
-                slist[64 + rank] = fp - lo;
+            for (int u = 0; u < NI; ++u) {
+                const int i = tid + 256 * u;
+                const int k = min(i / 18, hi - lo - 1);
+                ie[u] = a.f2e[fs + lo + k];
             }
-            __builtin_amdgcn_wave_barrier();   // same wave, LDS in issue order: the list is complete for the reads below
-            for (int t0 = 0; t0 < 6 * cnt; t0 += 64) {
-                const int t = t0 + lane;
-                if (t < 6 * cnt) {
-                    const int k = t / 6, c = t - 6 * k;
-                    const double* __restrict__ bp = P + 6 * slist[k] + c;
-                    double b[6];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int i = tid + 256 * u;
+                v[u] = *reinterpret_cast<const double2*>(Zc + 36 * (int64_t)ie[u] + 2 * (i % 18));
+            }
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int i = tid + 256 * u;
+                if (i < (hi - lo) * 18)
+                    *reinterpret_cast<double2*>(&As[2 * i]) = v[u];
+            }
+        }
+        __syncthreads();
+        // The pair's terms of this pass, eight at a time: the eight (left, right) index pairs are loaded together, then
+        // the 48 right-operand values, so a batch pays two memory latencies instead of three per term (a lane walking
+        // its list term by term spends its time waiting: measured 115 us per launch at 500 x 200, 25 % visibility).
+#ifndef VMM_PAIR_TB
+#define VMM_PAIR_TB 8
+#endif
+        constexpr int TB = VMM_PAIR_TB;
+        while (active && t < t1) {
+            int2 tt[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+                tt[u] = terms[min(t + u, t1 - 1)];
+            double b[TB][6];
+            bool ok[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                ok[u] = t + u < t1 && tt[u].x < hi;   // a prefix: the terms are ordered by left position
+                if (rhs) {
 #pragma unroll
                     for (int r = 0; r < 6; ++r)
-                        b[r] = bp[r * rs];
-                    double* ap = acc + 6 * slist[64 + k] + c;
+                        b[u][r] = a.ze[6 * (int64_t)tt[u].y + r];
+                } else {
+                    const double* __restrict__ bp = Zc + 36 * (int64_t)tt[u].y + c;
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        double o = A[0][q] * b[0];
-#pragma unroll
-                        for (int r = 1; r < 6; ++r)
-                            o = fma(A[r][q], b[r], o);
-                        ap[q * W] += o;
-                    }
+                    for (int r = 0; r < 6; ++r)
+                        b[u][r] = bp[6 * r];
                 }
             }
-            __builtin_amdgcn_wave_barrier();   // the list is overwritten by the next chunk
+            int n_ok = 0;
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                if (ok[u]) {
+                    const double* __restrict__ Ap = As + 36 * (tt[u].x - lo);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+                            acc[q] = fma(Ap[6 * r + q], b[u][r], acc[q]);
+                    ++n_ok;
+                }
+            }
+            t += n_ok;
+            if (n_ok < TB)
+                break;   // the rest of the list belongs to a later pass (or the list is finished)
         }
     }
-    __syncthreads();
+    if (!active)
+        return;
     if (a.add_diag && a.ctl) {
         a.da.H_F += small_sel(a.ctl, a.da.alt_off);
         a.da.g_F += small_sel(a.ctl, a.da.alt_off);
     }
-    // the group's columns of rows 6f .. 6f+5; the last group also zeroes the rest of the diagonal 64-block
-    const bool last = hi == f + 1;
-    const int c0 = 6 * lo, c1 = last ? min(((6 * f + 6 + 63) / 64) * 64, ld) : 6 * hi;
-    const int ncol = c1 - c0;
-    for (int i = tid; i < 6 * ncol; i += 256) {
-        const int q = i / ncol, col = i - q * ncol;
-        const int gcol = c0 + col, row = 6 * f + q;
-        double v = (gcol < 6 * hi) ? -acc[q * W + col] : 0.0;
-        if (a.add_diag && gcol >= 6 * f && gcol < 6 * f + 6) {
-            const int b = gcol - 6 * f;
-            v += a.da.scale_F[row] * a.da.H_F[36 * (int64_t)f + 6 * q + b] * a.da.scale_F[gcol];
-            if (q == b)
+    if (rhs) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int col = 6 * f + q;
+            a.S[(int64_t)n_pad * ld + col] = (a.add_diag ? a.da.scale_F[col] * a.da.g_F[col] : 0.0) - acc[q];
+        }
+        return;
+    }
+    const int gcol = 6 * j + c;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int row = 6 * f + q;
+        double v = -acc[q];
+        if (a.add_diag && j == f) {
+            v += a.da.scale_F[row] * a.da.H_F[36 * (int64_t)f + 6 * q + c] * a.da.scale_F[gcol];
+            if (q == c)
                 v += a.da.D2_F[row];
         }
         a.S[(int64_t)row * ld + gcol] = v;
-    }
-    if (g == 0 && w == 0 && lane < 6) {
-        const int col = 6 * f + lane;
-        a.S[(int64_t)n_pad * ld + col] = (a.add_diag ? a.da.scale_F[col] * a.da.g_F[col] : 0.0) - bacc;
     }
 }
 
@@ -601,20 +630,21 @@ void launch_schur_rows(Engine& e, bool add_diag)
     if (e.n_row_items <= 0)
         return;
     const int f_off = e.elim_cams ? e.n_cams : 0;
-    RowArgs a;
+    PairArgs a;
     a.ctl = e.ctl;
-    a.items = e.row_items;
-    a.group_tags = e.row_group_tags;
-    a.n_f = e.n_f;
+    a.item_row = e.row_items;
+    a.item_p0 = e.row_items + e.n_row_items;
+    a.pair_start = e.pair_start;
+    a.tstart = e.pair_tstart;
+    a.terms = reinterpret_cast<const int2*>(e.pair_terms);
     a.f_start = e.ordF.start;
-    a.f_other = e.ordF.other;
     a.f2e = e.f2e;
-    a.e_start = e.ordE.start;
-    a.e_other = e.ordE.other;
     a.Zc = e.Zc;
     a.ze = e.ze;
     a.S = e.S;
     a.ld = e.ldz;
+    a.n_items = e.n_row_items;
+    a.n_f = e.n_f;
     a.da.H_F = e.elim_cams ? e.H_tag : e.H_cam;
     a.da.g_F = e.elim_cams ? e.g_tag : e.g_cam;
     a.da.scale_F = e.scale + 6 * (size_t)f_off;
@@ -623,8 +653,8 @@ void launch_schur_rows(Engine& e, bool add_diag)
     a.da.n_pad = e.n_pad;
     a.da.alt_off = e.small_alt_off;
     a.add_diag = add_diag ? 1 : 0;
-    const size_t lds = sizeof(double) * 36 * (size_t)e.row_group_tags + sizeof(int) * 4 * 128;
-    hipLaunchKernelGGL(k_schur_rows, dim3(e.n_row_items), dim3(256), lds, e.stream, a);
+    const int n_fill = std::min(64, e.n_pad + 1);   // workgroups for the rows' zero fill and the padding
+    hipLaunchKernelGGL(k_schur_pairs, dim3(e.n_row_items + n_fill), dim3(256), 0, e.stream, a);
 }
 
 void launch_syrk_only(Engine& e)
@@ -708,7 +738,7 @@ int preload_schur_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<float, false>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<double, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<float, true>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_schur_rows)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_schur_pairs)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_syrk_streamk)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<false>)) != hipSuccess;

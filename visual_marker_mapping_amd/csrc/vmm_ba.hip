@@ -363,6 +363,7 @@ static int setup_lookahead(Engine& e, int n_blk_max, int ld)
     (void)n_blk_max;
     e.P2[0] = e.P;
     e.P2[1] = e.P + (size_t)kNB * ld;
+    e.P2[2] = e.P + (size_t)2 * kNB * ld;
     return VMM_BA_OK;
 }
 
@@ -1217,28 +1218,103 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     }
     if (e.sparse_schur) {
         if ((rc = dev_alloc(e, &e.Zc, (size_t)36 * std::max<int64_t>(e.n_obs, 1)))) return fail(rc);
-        std::vector<int32_t> posE((size_t)e.n_obs), f2e((size_t)e.n_obs);
+        // F-order <-> E-order positions of an observation
+        std::vector<int32_t> posE((size_t)e.n_obs), f2e((size_t)e.n_obs), row_pos((size_t)e.n_obs);
         for (int64_t d = 0; d < e.n_obs; ++d)
             posE[(size_t)callerE[(size_t)d]] = (int32_t)d;
-        for (int64_t d = 0; d < e.n_obs; ++d)
-            f2e[(size_t)d] = posE[(size_t)callerF[(size_t)d]];
-        if ((rc = dev_alloc(e, &e.f2e, f2e.size()))) return fail(rc);
-        if ((rc = upload(e, e.f2e, f2e))) return fail(rc);
-        // work items of k_schur_rows: (kept pose, column group), the longest rows first; the accumulator of a group
-        // (6 x 6 group_tags doubles) stays under 64 KB of LDS, two workgroups per CU
-        const int max_tags = 220;
-        const int n_grp = (e.n_f + max_tags - 1) / max_tags;
-        e.row_group_tags = (e.n_f + n_grp - 1) / n_grp;
-        std::vector<int32_t> items;
-        for (int f = e.n_f - 1; f >= 0; --f)
-            for (int g = 0; g * e.row_group_tags <= f; ++g) {
-                items.push_back(f);
-                items.push_back(g);
+        for (int fq = 0; fq < e.n_f; ++fq)
+            for (int32_t d = startF[fq]; d < startF[fq + 1]; ++d) {
+                f2e[(size_t)d] = posE[(size_t)callerF[(size_t)d]];
+                row_pos[(size_t)f2e[(size_t)d]] = d - startF[fq];   // position of the observation in its kept pose's row
             }
-        items.push_back(e.n_f);   // the padding rows
-        items.push_back(0);
-        e.n_row_items = (int)(items.size() / 2);
+        // The symbolic structure of S -= Z^T Z, once per problem (the counterpart of the symbolic phase of the sparse
+        // Cholesky behind ceres::Solve): row f owns the pairs (f, f' = 0..f) and, last, its right-hand side entry.
+        // A term of pair (f, f') = two observations (e, f), (e, f') of one eliminated pose; terms are listed in e
+        // order (that is the summation order), the left block by its position in f's row (the kernel stages the
+        // row's blocks in LDS), the right block by its E-order index.
+        std::vector<int32_t> pstart((size_t)e.n_f + 1, 0);
+        for (int fq = 0; fq < e.n_f; ++fq)
+            pstart[(size_t)fq + 1] = pstart[(size_t)fq] + fq + 2;
+        const size_t n_pairs = (size_t)pstart[(size_t)e.n_f];
+        std::vector<int32_t> tstart(n_pairs + 1, 0);
+        for (int q = 0; q < e.n_e; ++q)
+            for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1) {
+                const int f1 = otherE[(size_t)d1];
+                tstart[(size_t)pstart[(size_t)f1] + f1 + 1 + 1]++;   // rhs pair of row f1
+                for (int32_t d2 = startE[q]; d2 < startE[q + 1]; ++d2) {
+                    const int f2 = otherE[(size_t)d2];
+                    if (f2 <= f1)
+                        tstart[(size_t)pstart[(size_t)f1] + f2 + 1]++;
+                }
+            }
+        for (size_t k = 0; k < n_pairs; ++k)
+            tstart[k + 1] += tstart[k];
+        const size_t n_terms = (size_t)tstart[n_pairs];
+        if (n_terms >= ((size_t)1 << 31)) {
+            set_error("block-sparse elimination: more than 2^31 block products (set VMM_BA_SCHUR=dense)");
+            return fail(VMM_BA_ERR_ARGUMENT);
+        }
+        std::vector<int32_t> ta(n_terms), tb(n_terms), fill(tstart.begin(), tstart.end() - 1);
+        for (int q = 0; q < e.n_e; ++q)
+            for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1) {
+                const int f1 = otherE[(size_t)d1];
+                {
+                    const int32_t k = fill[(size_t)pstart[(size_t)f1] + f1 + 1]++;
+                    ta[(size_t)k] = row_pos[(size_t)d1];
+                    tb[(size_t)k] = q;
+                }
+                for (int32_t d2 = startE[q]; d2 < startE[q + 1]; ++d2) {
+                    const int f2 = otherE[(size_t)d2];
+                    if (f2 > f1)
+                        continue;
+                    const int32_t k = fill[(size_t)pstart[(size_t)f1] + f2]++;
+                    ta[(size_t)k] = row_pos[(size_t)d1];
+                    tb[(size_t)k] = d2;
+                }
+            }
+        // the kernel walks a pair's terms pass by pass of 128 left blocks: terms must be ordered by left position.
+        // They are listed in e order; a row's positions follow the caller's order, which need not be e order.
+        for (size_t k = 0; k < n_pairs; ++k) {
+            const int32_t t0 = tstart[k], t1 = tstart[k + 1];
+            bool sorted = true;
+            for (int32_t t = t0 + 1; t < t1 && sorted; ++t)
+                sorted = ta[(size_t)t - 1] <= ta[(size_t)t];
+            if (!sorted) {
+                std::vector<std::pair<int32_t, int32_t>> tmp;
+                for (int32_t t = t0; t < t1; ++t)
+                    tmp.emplace_back(ta[(size_t)t], tb[(size_t)t]);
+                std::stable_sort(tmp.begin(), tmp.end(),
+                                 [](const std::pair<int32_t, int32_t>& x, const std::pair<int32_t, int32_t>& y) { return x.first < y.first; });
+                for (int32_t t = t0; t < t1; ++t) {
+                    ta[(size_t)t] = tmp[(size_t)(t - t0)].first;
+                    tb[(size_t)t] = tmp[(size_t)(t - t0)].second;
+                }
+            }
+        }
+        // work items: up to 42 consecutive pairs of one row (6 lanes per pair); rows with many pairs first
+        std::vector<int32_t> item_row, item_p0;
+        for (int fq = e.n_f - 1; fq >= 0; --fq)
+            for (int j0 = 0; j0 < fq + 2; j0 += 42) {
+                item_row.push_back(fq);
+                item_p0.push_back(pstart[(size_t)fq] + j0);
+            }
+        e.n_row_items = (int)item_row.size();
+        std::vector<int32_t> items(item_row);
+        items.insert(items.end(), item_p0.begin(), item_p0.end());
+        if ((rc = dev_alloc(e, &e.f2e, f2e.size()))) return fail(rc);
+        if ((rc = dev_alloc(e, &e.pair_start, pstart.size()))) return fail(rc);
+        if ((rc = dev_alloc(e, &e.pair_tstart, tstart.size()))) return fail(rc);
+        std::vector<int32_t> tt(2 * std::max<size_t>(n_terms, 1), 0);
+        for (size_t k = 0; k < n_terms; ++k) {
+            tt[2 * k] = ta[k];
+            tt[2 * k + 1] = tb[k];
+        }
+        if ((rc = dev_alloc(e, &e.pair_terms, tt.size()))) return fail(rc);
         if ((rc = dev_alloc(e, &e.row_items, items.size()))) return fail(rc);
+        if ((rc = upload(e, e.f2e, f2e))) return fail(rc);
+        if ((rc = upload(e, e.pair_start, pstart))) return fail(rc);
+        if ((rc = upload(e, e.pair_tstart, tstart))) return fail(rc);
+        if ((rc = upload(e, e.pair_terms, tt))) return fail(rc);
         if ((rc = upload(e, e.row_items, items))) return fail(rc);
         if (hipStreamSynchronize(e.stream) != hipSuccess) {   // host vectors go out of scope
             set_error("create: upload of the block-sparse plan failed");
@@ -1249,7 +1325,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     }
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
     if (e.multi && (rc = dev_alloc(e, &e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2))) return fail(rc);
-    if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.P, (size_t)3 * kNB * e.ldz))) return fail(rc);
     if ((rc = setup_lookahead(e, e.n_blk, e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
@@ -1851,7 +1927,7 @@ static int make_scratch(Engine& e, int device, int ld)
             e.n_cu = prop.multiProcessorCount;
     }
     int rc;
-    if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * ld))) return rc;
+    if ((rc = dev_alloc(e, &e.P, (size_t)3 * kNB * ld))) return rc;
     if ((rc = setup_lookahead(e, ld / kNB, ld))) return rc;
     if ((rc = dev_alloc(e, &e.dinv, (size_t)ld + kNB))) return rc;
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(ld / kNB + 1) * 4096))) return rc;
@@ -2114,6 +2190,99 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     return restore_raw();
+}
+
+// Diagnostic behind DESIGN.md's question "can the reduced-system assembly hide behind the factorisation?": times, with
+// HIP events, (0) rank-k update + partial-tile sum alone, (1) factorisation + triangular solves alone, (2) both back to
+// back on one stream (today's order), (3) both at once on two streams -- the factorisation on a valid S, the rank-k
+// update of the same Z writing its sum into a scratch matrix, so that only the sharing of the chip is measured, not a
+// dependency.  Dense elimination, one GPU.  ms[4] averages over reps.
+int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
+{
+    if (!h || !ms || reps <= 0) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    Engine& e = *reinterpret_cast<Engine*>(h);
+    if (e.multi || e.sparse_schur || !e.Z) {
+        set_error("debug_overlap needs a single-GPU handle on the dense elimination path");
+        return VMM_BA_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(e.device));
+    int rc;
+    if ((rc = flush_state(e))) return rc;
+    vmm_ba_options o;
+    vmm_ba_default_options(&o);
+    o.max_num_iterations = 1 << 30;
+    o.function_tolerance = o.parameter_tolerance = o.gradient_tolerance = 0.0;
+    if (e.trace_capacity < 1) {
+        if ((rc = dev_alloc(e, &e.trace, 1, false))) return rc;
+        e.trace_capacity = 1;
+        drop_graphs(e);
+    }
+    if ((rc = begin_lm_loop(e, o, 0))) return rc;
+    if ((rc = enqueue_iteration(e, o))) return rc;   // populates Z, the small blocks and the control block
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    double* S2 = nullptr;
+    hipStream_t sb = nullptr;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipError_t err = hipMalloc((void**)&S2, sizeof(double) * (size_t)e.ldz * e.ldz);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && err == hipSuccess; ++i)
+        err = hipEventCreate(&ev[i]);
+    auto reset_flags = [&]() -> hipError_t {
+        hipError_t r = hipMemcpy(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost);
+        if (r != hipSuccess) return r;
+        e.ctl_host->done = 0;
+        e.ctl_host->lin_fail = 0;
+        e.ctl_host->sync_timeout = 0;
+        return hipMemcpy(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice);
+    };
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+    for (int r = 0; r < reps + 1 && err == hipSuccess; ++r) {   // repetition 0 is untimed
+        float t[4] = { 0.f, 0.f, 0.f, 0.f };
+        // (0) rank-k update + sum (leaves a valid S), (1) factorisation + solves
+        if ((err = reset_flags()) != hipSuccess) break;
+        (void)hipEventRecord(ev[0], e.stream);
+        launch_syrk_reduced(e);
+        (void)hipEventRecord(ev[1], e.stream);
+        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
+        (void)hipEventRecord(ev[2], e.stream);
+        if ((err = hipEventSynchronize(ev[2])) != hipSuccess) break;
+        (void)hipEventElapsedTime(&t[0], ev[0], ev[1]);
+        (void)hipEventElapsedTime(&t[1], ev[1], ev[2]);
+        (void)hipEventElapsedTime(&t[2], ev[0], ev[2]);
+        // (3) both at once: S rebuilt first (untimed), then the factorisation beside a second rank-k update into S2
+        if ((err = reset_flags()) != hipSuccess) break;
+        launch_syrk_reduced(e);
+        if ((err = hipStreamSynchronize(e.stream)) != hipSuccess) break;
+        (void)hipEventRecord(ev[0], e.stream);
+        (void)hipStreamWaitEvent(sb, ev[0], 0);
+        launch_syrk_plan(sb, e.ctl, e.Z, e.ldz, e.syrk);
+        launch_reduce_plan(sb, e.ctl, e.syrk, e.ldz, e.n_pad + 1, S2);
+        (void)hipEventRecord(ev[1], sb);
+        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
+        (void)hipStreamWaitEvent(e.stream, ev[1], 0);
+        (void)hipEventRecord(ev[2], e.stream);
+        if ((err = hipEventSynchronize(ev[2])) != hipSuccess) break;
+        (void)hipEventElapsedTime(&t[3], ev[0], ev[2]);
+        if (r > 0)
+            for (int i = 0; i < 4; ++i)
+                acc[i] += t[i];
+    }
+    if (err == hipSuccess)
+        err = hipGetLastError();
+    for (auto& x : ev)
+        if (x) (void)hipEventDestroy(x);
+    if (sb) (void)hipStreamDestroy(sb);
+    (void)hipFree(S2);
+    if (err != hipSuccess) {
+        set_error(std::string("debug_overlap: ") + hipGetErrorString(err));
+        return VMM_BA_ERR_HIP;
+    }
+    for (int i = 0; i < 4; ++i)
+        ms[i] = acc[i] / reps;
+    return VMM_BA_OK;
 }
 
 } // extern "C"

@@ -176,6 +176,12 @@ class BundleAdjuster:
                                                  _ptr(V), _ptr(U), _ptr(W), _ptr(gc), _ptr(gt)))
         return {"cost": c.value, "V": V, "U": U, "W": W, "g_cam": gc, "g_tag": gt}
 
+    def debug_overlap(self, reps=10):
+        """ms of: rank-k update + sum alone, factorisation + solves alone, both back to back, both at once on two streams."""
+        out = np.zeros(4)
+        _lib.check(_lib.lib().vmm_ba_debug_overlap(self._h, int(reps), _ptr(out)))
+        return dict(zip(("syrk_ms", "cholesky_ms", "sequential_ms", "concurrent_ms"), out.tolist()))
+
     def time_kernels(self, options=None, reps=5):
         o = options or default_options()
         t = _lib.KernelTimes()
