@@ -171,11 +171,11 @@ struct Engine {
     double* Z = nullptr;            // [k_pad][ldz] dense L_e^{-1} W (+ z column), row-major
     int k_dim = 0, k_pad = 0;
     int n_red = 0, n_pad = 0, ldz = 0, n_blk = 0;   // reduced order, padded, leading dim, blocks
-    // Block-sparse elimination (kernels_sparse.hip): Z holds only the 6x6 blocks of co-observed (e, f) pairs and
+    // Block-sparse elimination (kernels_schur.hip: k_schur_pairs): Z holds only the 6x6 blocks of co-observed (e, f) pairs and
     // S -= Z^T Z runs over pairs that share an eliminated pose.  Chosen at create by a cost model (VMM_BA_SCHUR=
     // dense|sparse overrides): at full visibility the dense MFMA rank-k update is the faster one.
     bool sparse_schur = false;
-    double* Zc = nullptr;           // [n_obs][36]: one row-major 6x6 block per observation, E order
+    double* Zc = nullptr;           // [n_obs][36]: one column-major 6x6 block per observation, E order
     int32_t* f2e = nullptr;         // [n_obs] F-order position -> E-order position of the same observation
     // the symbolic structure of S -= Z^T Z (built once at create): pairs of kept poses (row f: f' = 0..f, then the rhs),
     // the terms of every pair, and the work items of k_schur_pairs (row | first pair; up to 42 pairs of one row each)
@@ -189,8 +189,8 @@ struct Engine {
     SyrkPlan syrk;                  // stream-K plan of S = Z^T Z
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
     double* S_packed = nullptr;     // world > 1: rows 0..n_pad of the lower triangle, packed, for the all-reduce
-    double* P = nullptr;            // [3][kNB][ldz] transposed Cholesky panels (rotating: the trailing updates apply two at a time)
-    double* P2[3] = { nullptr, nullptr, nullptr };
+    double* P = nullptr;            // [2][kNB][ldz] transposed Cholesky panels (alternating)
+    double* P2[2] = { nullptr, nullptr };
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
     double* Ldiag = nullptr;        // [n_blk][64][64] Cholesky factors of the diagonal blocks
     double* Linv = nullptr;         // [n_blk][64][64] their inverses (all but the last block)
@@ -263,6 +263,8 @@ void launch_project(hipStream_t st, const Intrinsics& K, int64_t n, const double
 void launch_sum(Engine& e, bool guard, const double* in, int n, double* out);
 // kernels_schur.hip
 void launch_elim(Engine& e);
+void launch_schur_rows(Engine& e, bool add_diag);   // block-sparse: S from the pair lists (k_schur_pairs)
+int schur_pairs_per_item();                           // pairs of one row a workgroup of k_schur_pairs takes
 void launch_syrk_only(Engine& e);
 void launch_syrk_reduced(Engine& e);
 void launch_add_diag(Engine& e);

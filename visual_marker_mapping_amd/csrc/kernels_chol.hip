@@ -239,7 +239,6 @@ __device__ __forceinline__ void panel_round(const int w, const int lane,
 template <bool HAS_T>
 __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
                                            double* __restrict__ P, const double* __restrict__ Pprev,
-                                           const double* __restrict__ Pprev2,
                                            double* __restrict__ dinv, double* __restrict__ Ld, double* RA,
                                            double* Pd, double* Pt, double* invd, double* Ads, double* Ats)
 {
@@ -269,27 +268,20 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
             }
         }
     }
-    // Look-ahead: the trailing updates skip block column k (the update workgroups of launch k start at column k+1),
-    // so this kernel does not have to wait for them; the missing rank-64 updates of the tiles (k,k) and (i,k) are
-    // applied here from the transposed panels (64 x ld) of the previous launches: panel k-1 always, panel k-2 too when
-    // k is even -- the update workgroups apply the panels in PAIRS (k-2, k-1), every second launch (chol_update_wg).
+    // Look-ahead: the trailing update of panel k-1 skips block column k (k_chol_update starts at column
+    // k+1 of ITS panel), so this kernel does not have to wait for it; the missing rank-64 update of the
+    // tiles (k,k) and (i,k) is applied here from the previous transposed panel Pprev (64 x ld).
     STAMP(6);
-#pragma unroll 1
-    for (int pp = 0; pp < 2; ++pp) {
-        const double* __restrict__ Pp = pp == 0 ? Pprev2 : Pprev;
-        if (!Pp)
-            continue;
-        if (pp == 1 && Pprev2)
-            __syncthreads();   // the staged operands of the older panel are no longer read
-        // stage Pp[:, K0..K0+63] (diagonal rows; also the B operand) and Pp[:, R0..R0+63] k-major
+    if (Pprev) {
+        // stage Pprev[:, K0..K0+63] (diagonal rows; also the B operand) and Pprev[:, R0..R0+63] k-major
         double2 va[8], vt[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int idx = it * 256 + tid;
             const int mm = idx >> 5, c = (idx & 31) * 2;
-            va[it] = *reinterpret_cast<const double2*>(Pp + (int64_t)mm * ld + K0 + c);
+            va[it] = *reinterpret_cast<const double2*>(Pprev + (int64_t)mm * ld + K0 + c);
             if (HAS_T)
-                vt[it] = *reinterpret_cast<const double2*>(Pp + (int64_t)mm * ld + R0 + c);
+                vt[it] = *reinterpret_cast<const double2*>(Pprev + (int64_t)mm * ld + R0 + c);
         }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -364,7 +356,6 @@ constexpr int kStepSmem = kPanelSmem > kUpdateSmem ? kPanelSmem : kUpdateSmem;
 
 __device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
                                               double* __restrict__ P, const double* __restrict__ Pprev,
-                                              const double* __restrict__ Pprev2,
                                               double* __restrict__ dinv, double* __restrict__ Ld, double* smem)
 {
     double* RA = smem;                     // workgroup 0: L^T (stride kLdT); others: result tile R (stride kLd)
@@ -374,9 +365,9 @@ __device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S
     double* Ads = invd + 64;               // previous panel, diagonal rows (k-major); 16-byte aligned offsets
     double* Ats = Ads + 64 * kLdsRow;      // previous panel, this workgroup's rows
     if (blockIdx.x == 0)
-        panel_body<false>(ctl, S, ld, n_pad, k, P, Pprev, Pprev2, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
+        panel_body<false>(ctl, S, ld, n_pad, k, P, Pprev, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
     else
-        panel_body<true>(ctl, S, ld, n_pad, k, P, Pprev, Pprev2, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
+        panel_body<true>(ctl, S, ld, n_pad, k, P, Pprev, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
 }
 
 #ifdef VMM_STAMPS
@@ -410,16 +401,13 @@ __device__ __forceinline__ void update_tile_index(int n_blk, int k, int t, int& 
     }
 }
 
-// Workgroup u of n_wg takes the tiles u, u + n_wg, ...  A tile receives the rank-64 updates of TWO panels per visit
-// (PA: panel k-1, PB: panel k, both transposed, 64 x ld): its C values are read and written once for 2 x 64 k-steps,
-// which halves the HBM traffic that bounds a rank-64 update (16 B per 128 flops).  With more tiles than compute
-// units the operands of the NEXT pass (this tile's second panel, then the next tile's first) are requested before
-// the MFMAs of the current one and parked in the other half of the LDS, and the C tile is requested at the start of
-// its first pass and only added after the second: a pass costs its MFMAs plus one barrier instead of a full memory
-// latency.  No register array lives across the loop back-edge (those end up in scratch).
+// Workgroup u of n_wg takes the tiles u, u + n_wg, ...  With more tiles than compute units (large reduced
+// systems) the operands of the NEXT tile are requested before the MFMAs of the current one and parked in
+// the other half of the LDS, and the C tile is requested at the start of its own iteration and only added
+// after the 16 k-steps: a tile costs its MFMAs plus one barrier instead of a full memory latency.  No
+// register array lives across the loop back-edge (those end up in scratch).
 __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, int n_blk, int k, int u, int n_wg,
-                                               int n_tiles, const double* __restrict__ PA,
-                                               const double* __restrict__ PB, double* smem)
+                                               int n_tiles, const double* __restrict__ P, double* smem)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -435,8 +423,8 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
         for (int it = 0; it < 8; ++it) {
             const int idx = it * 256 + tid;
             const int m = idx >> 5, c = (idx & 31) * 2;
-            va[it] = *reinterpret_cast<const double2*>(PA + (int64_t)m * ld + bi * kNB + c);
-            vb[it] = *reinterpret_cast<const double2*>(PA + (int64_t)m * ld + bj * kNB + c);   // diagonal tile: same lines
+            va[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + bi * kNB + c);
+            vb[it] = *reinterpret_cast<const double2*>(P + (int64_t)m * ld + bj * kNB + c);   // diagonal tile: same lines
         }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -449,8 +437,10 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
     __syncthreads();
     int cur = 0;
     for (int t = u; t < n_tiles; t += n_wg) {
+        const double* As = smem + cur * 128 * kLdsRow;
+        const double* Bs = As + 64 * kLdsRow;
         const int I0 = bi * kNB, J0 = bj * kNB;
-        // The requests of this tile's C values and of the next pass's operands are issued as volatile asm:
+        // The requests of this tile's C values and of the NEXT tile's operands are issued as volatile asm:
         // written as plain loads, LLVM sinks them below the MFMA loop to their first use (measured: the
         // memory latency then adds to the MFMA time, 6.6 us per tile instead of ~3).  The results are only
         // touched after the matching s_waitcnt below, which takes them as read-write operands.
@@ -479,165 +469,99 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
             }
             nbj = k + 2 + off;
         }
+        double2v va[8], vb[8];
+        const double* pa[8];
+        const double* pb[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            pa[it] = P + (int64_t)m * ld + nbi * kNB + c;
+            pb[it] = P + (int64_t)m * ld + nbj * kNB + c;
+        }
+        USTAMP(41);
         double4_t acc[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
                 acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-        // ---- pass 0: panel PA from the LDS half `cur`; requests this tile's C values and its PB operands ----
-        {
-            const double* As = smem + cur * 128 * kLdsRow;
-            const double* Bs = As + 64 * kLdsRow;
-            double2v va[8], vb[8];
-            const double* pa[8];
-            const double* pb[8];
+        // 16 k-steps; the LDS operands of step ks+1 are read before the MFMAs of step ks, and one of the 16
+        // operand requests of the next tile is issued per step (VMEM issue slots beside the MFMAs)
+        double a0 = -As[fk * kLdsRow + wi * 32 + fi], a1 = -As[fk * kLdsRow + wi * 32 + 16 + fi];
+        double b0 = Bs[fk * kLdsRow + wj * 32 + fi], b1 = Bs[fk * kLdsRow + wj * 32 + 16 + fi];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * 256 + tid;
-                const int m = idx >> 5, c = (idx & 31) * 2;
-                pa[it] = PB + (int64_t)m * ld + bi * kNB + c;
-                pb[it] = PB + (int64_t)m * ld + bj * kNB + c;
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks < 8) {   // this tile's C values (HBM, the longer latency) first ...
+                __asm__ volatile("global_load_dwordx2 %0, %1, off"
+                                 : "=&v"(creg[(2 * ks) >> 3][((2 * ks) >> 2) & 1][(2 * ks) & 3]) : "v"(pc[2 * ks]) : "memory");
+                __asm__ volatile("global_load_dwordx2 %0, %1, off"
+                                 : "=&v"(creg[(2 * ks + 1) >> 3][((2 * ks + 1) >> 2) & 1][(2 * ks + 1) & 3]) : "v"(pc[2 * ks + 1]) : "memory");
+            } else {        // ... then the next tile's operands (L2)
+                __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[ks - 8]) : "v"(pa[ks - 8]) : "memory");
+                __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[ks - 8]) : "v"(pb[ks - 8]) : "memory");
             }
-            USTAMP(41);
-            // 16 k-steps; the LDS operands of step ks+1 are read before the MFMAs of step ks, and one pair of requests
-            // is issued per step (VMEM issue slots beside the MFMAs)
-            double a0 = -As[fk * kLdsRow + wi * 32 + fi], a1 = -As[fk * kLdsRow + wi * 32 + 16 + fi];
-            double b0 = Bs[fk * kLdsRow + wj * 32 + fi], b1 = Bs[fk * kLdsRow + wj * 32 + 16 + fi];
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                if (ks < 8) {   // this tile's C values (HBM, the longer latency) first ...
-                    __asm__ volatile("global_load_dwordx2 %0, %1, off"
-                                     : "=&v"(creg[(2 * ks) >> 3][((2 * ks) >> 2) & 1][(2 * ks) & 3]) : "v"(pc[2 * ks]) : "memory");
-                    __asm__ volatile("global_load_dwordx2 %0, %1, off"
-                                     : "=&v"(creg[(2 * ks + 1) >> 3][((2 * ks + 1) >> 2) & 1][(2 * ks + 1) & 3]) : "v"(pc[2 * ks + 1]) : "memory");
-                } else {        // ... then the second panel's operands (L2)
-                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[ks - 8]) : "v"(pa[ks - 8]) : "memory");
-                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[ks - 8]) : "v"(pb[ks - 8]) : "memory");
-                }
-                double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
-                if (ks < 15) {
-                    const int row = ((ks + 1) * 4 + fk) * kLdsRow;
-                    na0 = -As[row + wi * 32 + fi];
-                    na1 = -As[row + wi * 32 + 16 + fi];
-                    nb0 = Bs[row + wj * 32 + fi];
-                    nb1 = Bs[row + wj * 32 + 16 + fi];
-                }
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-                a0 = na0;
-                a1 = na1;
-                b0 = nb0;
-                b1 = nb1;
+            double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
+            if (ks < 15) {
+                const int row = ((ks + 1) * 4 + fk) * kLdsRow;
+                na0 = -As[row + wi * 32 + fi];
+                na1 = -As[row + wi * 32 + 16 + fi];
+                nb0 = Bs[row + wj * 32 + fi];
+                nb1 = Bs[row + wj * 32 + 16 + fi];
             }
-            USTAMP(42);
-            __asm__ volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(creg[0][0][0]), "+v"(creg[0][0][1]), "+v"(creg[0][0][2]), "+v"(creg[0][0][3]),
-                               "+v"(creg[0][1][0]), "+v"(creg[0][1][1]), "+v"(creg[0][1][2]), "+v"(creg[0][1][3]),
-                               "+v"(creg[1][0][0]), "+v"(creg[1][0][1]), "+v"(creg[1][0][2]), "+v"(creg[1][0][3])
-                             :
-                             : "memory");
-            __asm__ volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(creg[1][1][0]), "+v"(creg[1][1][1]), "+v"(creg[1][1][2]), "+v"(creg[1][1][3]),
-                               "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]),
-                               "+v"(va[7])
-                             :
-                             : "memory");
-            __asm__ volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]),
-                               "+v"(vb[7])
-                             :
-                             : "memory");
-            USTAMP(43);
-            // park the second panel's operands in the other half (nobody reads it during this pass)
-            double* An = smem + (cur ^ 1) * 128 * kLdsRow;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * 256 + tid;
-                const int m = idx >> 5, c = (idx & 31) * 2;
-                *reinterpret_cast<double2v*>(&An[m * kLdsRow + c]) = va[it];
-                *reinterpret_cast<double2v*>(&An[(64 + m) * kLdsRow + c]) = vb[it];
-            }
-            __syncthreads();
-            cur ^= 1;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = na0;
+            a1 = na1;
+            b0 = nb0;
+            b1 = nb1;
         }
-        // ---- pass 1: panel PB; requests the next tile's PA operands; then C + both updates go back ----
-        {
-            const double* As = smem + cur * 128 * kLdsRow;
-            const double* Bs = As + 64 * kLdsRow;
-            double2v va[8], vb[8];
-            const double* pa[8];
-            const double* pb[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * 256 + tid;
-                const int m = idx >> 5, c = (idx & 31) * 2;
-                pa[it] = PA + (int64_t)m * ld + nbi * kNB + c;
-                pb[it] = PA + (int64_t)m * ld + nbj * kNB + c;
-            }
-            double a0 = -As[fk * kLdsRow + wi * 32 + fi], a1 = -As[fk * kLdsRow + wi * 32 + 16 + fi];
-            double b0 = Bs[fk * kLdsRow + wj * 32 + fi], b1 = Bs[fk * kLdsRow + wj * 32 + 16 + fi];
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                if (ks < 8)
-                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[ks]) : "v"(pa[ks]) : "memory");
-                else
-                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[ks - 8]) : "v"(pb[ks - 8]) : "memory");
-                double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
-                if (ks < 15) {
-                    const int row = ((ks + 1) * 4 + fk) * kLdsRow;
-                    na0 = -As[row + wi * 32 + fi];
-                    na1 = -As[row + wi * 32 + 16 + fi];
-                    nb0 = Bs[row + wj * 32 + fi];
-                    nb1 = Bs[row + wj * 32 + 16 + fi];
-                }
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-                a0 = na0;
-                a1 = na1;
-                b0 = nb0;
-                b1 = nb1;
-            }
 #ifdef VMM_STAMPS
-            __asm__ volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]) : "memory");
+        __asm__ volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][1][3]) : "memory");
 #endif
-            __asm__ volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]),
-                               "+v"(va[7])
-                             :
-                             : "memory");
-            __asm__ volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]),
-                               "+v"(vb[7])
-                             :
-                             : "memory");
+        USTAMP(42);
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(creg[0][0][0]), "+v"(creg[0][0][1]), "+v"(creg[0][0][2]), "+v"(creg[0][0][3]),
+                           "+v"(creg[0][1][0]), "+v"(creg[0][1][1]), "+v"(creg[0][1][2]), "+v"(creg[0][1][3]),
+                           "+v"(creg[1][0][0]), "+v"(creg[1][0][1]), "+v"(creg[1][0][2]), "+v"(creg[1][0][3])
+                         :
+                         : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(creg[1][1][0]), "+v"(creg[1][1][1]), "+v"(creg[1][1][2]), "+v"(creg[1][1][3]),
+                           "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]),
+                           "+v"(va[7])
+                         :
+                         : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]),
+                           "+v"(vb[7])
+                         :
+                         : "memory");
+        USTAMP(43);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi]
-                            = creg[a][b][r] + acc[a][b][r];
-            USTAMP(44);
-            // park the next tile's operands in the other half (nobody reads it during this pass)
-            double* An = smem + (cur ^ 1) * 128 * kLdsRow;
+                for (int r = 0; r < 4; ++r)
+                    S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi]
+                        = creg[a][b][r] + acc[a][b][r];
+        USTAMP(44);
+        // park the next tile's operands in the other half (nobody reads it during this iteration)
+        double* An = smem + (cur ^ 1) * 128 * kLdsRow;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * 256 + tid;
-                const int m = idx >> 5, c = (idx & 31) * 2;
-                *reinterpret_cast<double2v*>(&An[m * kLdsRow + c]) = va[it];
-                *reinterpret_cast<double2v*>(&An[(64 + m) * kLdsRow + c]) = vb[it];
-            }
-            USTAMP(45);
-            __syncthreads();
-            USTAMP(46);
-            cur ^= 1;
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            *reinterpret_cast<double2v*>(&An[m * kLdsRow + c]) = va[it];
+            *reinterpret_cast<double2v*>(&An[(64 + m) * kLdsRow + c]) = vb[it];
         }
+        USTAMP(45);
+        __syncthreads();
+        USTAMP(46);
+        cur ^= 1;
         bi = nbi;
         bj = nbj;
     }
@@ -1673,15 +1597,13 @@ __global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
         df2::role<false>(a, j, j, smem);
 }
 
-// One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their own
-// column from panel k-1 and, when k is even, panel k-2), the others -- in the launches with even k >= 2 -- apply the
-// trailing updates of the panels k-2 AND k-1 to the columns >= k+1, one read and one write of a tile for both
-// (a rank-64 update alone is HBM-bound at 16 B per 128 flops).  The two parts touch disjoint tiles and both only need
-// results of earlier launches, so the update (throughput work) runs beside the latency-bound panel.
+// One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their
+// own column from panel k-1), the others apply the trailing update of panel k-1 to the columns >= k+1.
+// The two parts touch disjoint tiles and both only need results of the previous launch, so the update
+// (throughput work) runs beside the latency-bound panel instead of in front of it.
 __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int n_blk,
                                                    int k, int n_panel, double* __restrict__ Pcur,
-                                                   const double* __restrict__ Pprev,
-                                                   const double* __restrict__ Pprev2, double* __restrict__ dinv,
+                                                   const double* __restrict__ Pprev, double* __restrict__ dinv,
                                                    double* __restrict__ Ld, double* __restrict__ Linv, int n_upd,
                                                    int n_upd_wg)
 {
@@ -1693,9 +1615,9 @@ __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restric
         return;
     __shared__ __attribute__((aligned(16))) double smem[kStepSmem];
     if ((int)blockIdx.x < n_panel)
-        chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, Pprev2, dinv, Ld, smem);
+        chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, dinv, Ld, smem);
     else if ((int)blockIdx.x < n_panel + n_upd_wg)
-        chol_update_wg(S, ld, n_blk, k - 1, (int)blockIdx.x - n_panel, n_upd_wg, n_upd, Pprev2, Pprev, smem);
+        chol_update_wg(S, ld, n_blk, k - 1, (int)blockIdx.x - n_panel, n_upd_wg, n_upd, Pprev, smem);
     else   // last workgroup of launches k >= 1: invert the diagonal factor of block k-1
         chol_inverse_wg(Ld + (int64_t)(k - 1) * 4096, dinv + (k - 1) * kNB, Linv + (int64_t)(k - 1) * 4096, smem);
 }
@@ -1755,16 +1677,13 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
     for (int k = 0; k < n_blk; ++k) {
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
         const int n_panel = 1 + (rows_below + 63) / 64;
-        // the trailing updates go in pairs of panels (k-2, k-1), in the launches with even k >= 2
-        const bool pair = k >= 2 && (k & 1) == 0;
-        const int n_upd = pair ? update_tiles(n_blk, k - 1) : 0;
+        const int n_upd = k > 0 ? update_tiles(n_blk, k - 1) : 0;
         // all workgroups of a launch resident at once (one per CU: 134 KB of LDS): the update workgroups
         // share the CUs the panel leaves free and loop over the tiles
         const int n_upd_wg = std::min(n_upd, std::max(e.n_cu - n_panel - 1, e.n_cu / 4));
         hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd_wg + (k > 0 ? 1 : 0)), dim3(256), 0, e.stream, ctl, S, ld,
-                           n_pad, n_blk, k, n_panel, e.P2[k % 3],
-                           k > 0 ? (const double*)e.P2[(k - 1) % 3] : (const double*)nullptr,
-                           pair ? (const double*)e.P2[(k - 2) % 3] : (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
+                           n_pad, n_blk, k, n_panel, e.P2[k & 1],
+                           k > 0 ? (const double*)e.P2[(k - 1) & 1] : (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
                            n_upd, n_upd_wg);
         if (getenv("VMM_BA_DEBUG")) {
             const hipError_t le = hipPeekAtLastError();

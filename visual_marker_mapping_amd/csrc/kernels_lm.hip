@@ -475,7 +475,7 @@ __device__ __forceinline__ void candidate_for_pose(const PoseViews& pv, const in
 // One wave per eliminated pose.
 // FUSE (one GPU): the candidate of every pose is formed here too -- an eliminated pose's by lane 0 of its wave, the
 // kept poses' by one thread each in the workgroups behind the eliminated family's -- instead of in k_candidate.
-// SPARSE: Z is the compressed Engine::Zc (one 6x6 block per observation, E order); the product with y_f gathers the
+// SPARSE: Z is the compressed Engine::Zc (one column-major 6x6 block per observation, E order); the product with y_f gathers the
 // kept poses of e's observations.
 template <bool FUSE, bool SPARSE>
 __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int e_off_pose,
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
             const double yv = yf[6 * (int64_t)e_other[es + k] + c];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                acc[i] += zp[36 * k + 6 * i + c] * yv;
+                acc[i] += zp[36 * k + 6 * c + i] * yv;   // Z(i, c) of block k, column-major
         }
     } else {
         const double* zr = Z + (int64_t)(6 * e) * ldz;

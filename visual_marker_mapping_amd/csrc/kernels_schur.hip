@@ -51,8 +51,9 @@ __device__ __forceinline__ bool chol6(double* A)
 // observation stores L_e, z_e and the rhs column of Z.  A pose without observations owns no thread: nobody reads
 // its L_e, and its rows of Z (zero since vmm_ba_create) stay zero -- also what a rank needs for a pose whose
 // observations live on another rank.
-// SPARSE: the block goes into the compressed Z (Engine::Zc: one row-major 6x6 block per observation, E order)
-// instead of into the dense matrix, and the rhs lives in ze only.
+// SPARSE: the block goes into the compressed Z (Engine::Zc: one COLUMN-major 6x6 block per observation, E order: a
+// column's six doubles are contiguous, so a lane of k_schur_pairs fetches its right-operand column with three 16-byte
+// loads) instead of into the dense matrix, and the rhs lives in ze only.
 template <typename WT, bool SPARSE>
 __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64_t n_pad,
                                                  const int32_t* __restrict__ own,
@@ -138,8 +139,13 @@ __global__ __launch_bounds__(256) void k_form_z(LmCtl* ctl, int64_t n_obs, int64
     int64_t rs = ldz;
     double* zrow = Z + (int64_t)(6 * e) * ldz + 6 * f;
     if (SPARSE) {
-        rs = 6;
-        zrow = Z + 36 * i;
+        double* zb = Z + 36 * i;
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                zb[6 * c + r] = X[6 * r + c];
+        return;
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -390,7 +396,7 @@ __global__ void k_add_diag(const LmCtl* ctl, int n_f, int f_off_pose, const doub
 // ---- block-sparse reduced system: S(f, f') -= sum over the eliminated poses e that see both f and f' --------------
 //
 // The dense path stores Z with its zero blocks and multiplies them (at 25 % visibility 15/16 of the rank-k flops);
-// here Z holds only the blocks of co-observed pairs (Engine::Zc, one row-major 6x6 block per observation, E order)
+// here Z holds only the blocks of co-observed pairs (Engine::Zc, one column-major 6x6 block per observation, E order)
 // and the product runs over pairs of observations that share an eliminated pose -- what the sparse normal-Cholesky
 // behind ceres::Solve (src/TagReconstructor.cpp:725-738) exploits on projects where an image sees a handful of tags
 // (README.md:155-216).  The structure is symbolic work done once at vmm_ba_create: for every pair of kept poses
@@ -404,7 +410,7 @@ __global__ void k_add_diag(const LmCtl* ctl, int n_f, int f_off_pose, const doub
 struct PairArgs {
     const LmCtl* ctl;
     const int32_t* item_row;    // [n_items] kept pose of the item
-    const int32_t* item_p0;     // [n_items] first pair (global pair id); the item ends at min(p0 + 42, end of the row)
+    const int32_t* item_p0;     // [n_items] first pair (global pair id); the item ends at min(p0 + kPairsPerItem, end of the row)
     const int32_t* pair_start;  // [n_f + 1] first pair id of every row; row f has the pairs f' = 0..f and the rhs
     const int32_t* tstart;      // [n_pairs + 1] term range of every pair
     const int2* terms;          // [n_terms] .x: position of the left block in the row's observation list, .y: E-order
@@ -419,8 +425,14 @@ struct PairArgs {
     int add_diag;
 };
 
-constexpr int kPairChunk = 128;   // left blocks staged per pass: 36 KB of LDS, four workgroups per CU
-constexpr int kPairsPerItem = 42; // 6 lanes per pair: 252 of 256 threads
+#ifndef VMM_PAIR_NS
+#define VMM_PAIR_NS 4
+#endif
+constexpr int kPairChunk = 128;   // left blocks staged per pass: 38 KB of LDS, four workgroups per CU
+constexpr int kPairSplit = VMM_PAIR_NS;                  // lanes that share one output column: each takes every
+                                                         // kPairSplit-th term, the partial sums meet in a fixed shuffle tree
+constexpr int kPairsPerItem = 256 / (6 * kPairSplit);    // 6 x kPairSplit lanes per pair
+constexpr int kPairBlk = 38;      // doubles per staged block: 36 + 2, so that consecutive blocks start 12 banks apart
 
 __global__ __launch_bounds__(256) void k_schur_pairs(PairArgs a)
 {
@@ -448,14 +460,15 @@ __global__ __launch_bounds__(256) void k_schur_pairs(PairArgs a)
         }
         return;
     }
-    __shared__ __attribute__((aligned(16))) double As[kPairChunk * 36];
+    __shared__ __attribute__((aligned(16))) double As[kPairChunk * kPairBlk];
     const int f = a.item_row[blockIdx.x];
     const int row_p0 = a.pair_start[f];
-    const int p = a.item_p0[blockIdx.x] + tid / 6, c = tid % 6;
+    const int sl = tid % kPairSplit;               // which of the pair's term subsequences
+    const int p = a.item_p0[blockIdx.x] + tid / (6 * kPairSplit), c = (tid / kPairSplit) % 6;
     const int j = p - row_p0;                      // f' (0..f) or f + 1: the right-hand side
-    const bool valid = tid < 6 * kPairsPerItem && j <= f + 1;
+    const bool valid = tid < 6 * kPairSplit * kPairsPerItem && j <= f + 1;
     const bool rhs = j == f + 1;
-    int t = valid ? a.tstart[p] : 0;
+    int t = valid ? a.tstart[p] + sl : 0;
     const int t1 = valid ? a.tstart[p + 1] : 0;
     const int fs = a.f_start[f], len = a.f_start[f + 1] - fs;
     const double* __restrict__ Zc = a.Zc;
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(PairArgs a)
             for (int u = 0; u < NI; ++u) {
                 const int i = tid + 256 * u;
                 if (i < (hi - lo) * 18)
-                    *reinterpret_cast<double2*>(&As[2 * i]) = v[u];
+                    *reinterpret_cast<double2*>(&As[kPairBlk * (i / 18) + 2 * (i % 18)]) = v[u];
             }
         }
         __syncthreads();
@@ -495,49 +508,59 @@ __global__ __launch_bounds__(256) void k_schur_pairs(PairArgs a)
         // the 48 right-operand values, so a batch pays two memory latencies instead of three per term (a lane walking
         // its list term by term spends its time waiting: measured 115 us per launch at 500 x 200, 25 % visibility).
 #ifndef VMM_PAIR_TB
-#define VMM_PAIR_TB 8
+#define VMM_PAIR_TB 4
 #endif
         constexpr int TB = VMM_PAIR_TB;
         while (active && t < t1) {
             int2 tt[TB];
 #pragma unroll
             for (int u = 0; u < TB; ++u)
-                tt[u] = terms[min(t + u, t1 - 1)];
+                tt[u] = terms[min(t + u * kPairSplit, t1 - 1)];
             double b[TB][6];
             bool ok[TB];
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
-                ok[u] = t + u < t1 && tt[u].x < hi;   // a prefix: the terms are ordered by left position
+                ok[u] = t + u * kPairSplit < t1 && tt[u].x < hi;   // a prefix: the terms are ordered by left position
                 if (rhs) {
 #pragma unroll
                     for (int r = 0; r < 6; ++r)
                         b[u][r] = a.ze[6 * (int64_t)tt[u].y + r];
                 } else {
-                    const double* __restrict__ bp = Zc + 36 * (int64_t)tt[u].y + c;
+                    // column c of the right block: 48 contiguous, 16-byte aligned bytes
+                    const double2* __restrict__ bp = reinterpret_cast<const double2*>(Zc + 36 * (int64_t)tt[u].y + 6 * c);
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
-                        b[u][r] = bp[6 * r];
+                    for (int r = 0; r < 3; ++r) {
+                        const double2 v2 = bp[r];
+                        b[u][2 * r] = v2.x;
+                        b[u][2 * r + 1] = v2.y;
+                    }
                 }
             }
             int n_ok = 0;
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
                 if (ok[u]) {
-                    const double* __restrict__ Ap = As + 36 * (tt[u].x - lo);
+                    const double* __restrict__ Ap = As + kPairBlk * (tt[u].x - lo);
 #pragma unroll
                     for (int r = 0; r < 6; ++r)
 #pragma unroll
                         for (int q = 0; q < 6; ++q)
-                            acc[q] = fma(Ap[6 * r + q], b[u][r], acc[q]);
+                            acc[q] = fma(Ap[6 * q + r], b[u][r], acc[q]);   // A(r, q), column-major
                     ++n_ok;
                 }
             }
-            t += n_ok;
+            t += n_ok * kPairSplit;
             if (n_ok < TB)
                 break;   // the rest of the list belongs to a later pass (or the list is finished)
         }
     }
-    if (!active)
+    // the kPairSplit partial sums of a column sit in neighbouring lanes: fixed tree
+#pragma unroll
+    for (int m = 1; m < kPairSplit; m <<= 1)
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            acc[q] += __shfl_xor(acc[q], m, 64);
+    if (!active || sl != 0)
         return;
     if (a.add_diag && a.ctl) {
         a.da.H_F += small_sel(a.ctl, a.da.alt_off);
@@ -624,6 +647,8 @@ void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int
         hipLaunchKernelGGL((k_reduce_partials<false>), dim3(16 * p.n_tiles), dim3(256), 0, st, ctl, plan_dev(p), ld, n_rows,
                            S, da);
 }
+
+int schur_pairs_per_item() { return kPairsPerItem; }
 
 void launch_schur_rows(Engine& e, bool add_diag)
 {

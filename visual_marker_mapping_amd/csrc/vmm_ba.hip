@@ -363,7 +363,6 @@ static int setup_lookahead(Engine& e, int n_blk_max, int ld)
     (void)n_blk_max;
     e.P2[0] = e.P;
     e.P2[1] = e.P + (size_t)kNB * ld;
-    e.P2[2] = e.P + (size_t)2 * kNB * ld;
     return VMM_BA_OK;
 }
 
@@ -1291,10 +1290,11 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
                 }
             }
         }
-        // work items: up to 42 consecutive pairs of one row (6 lanes per pair); rows with many pairs first
+        // work items: up to pairs_per_item() consecutive pairs of one row; rows with many pairs first
         std::vector<int32_t> item_row, item_p0;
+        const int ppi = schur_pairs_per_item();
         for (int fq = e.n_f - 1; fq >= 0; --fq)
-            for (int j0 = 0; j0 < fq + 2; j0 += 42) {
+            for (int j0 = 0; j0 < fq + 2; j0 += ppi) {
                 item_row.push_back(fq);
                 item_p0.push_back(pstart[(size_t)fq] + j0);
             }
@@ -1325,7 +1325,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     }
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
     if (e.multi && (rc = dev_alloc(e, &e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2))) return fail(rc);
-    if ((rc = dev_alloc(e, &e.P, (size_t)3 * kNB * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * e.ldz))) return fail(rc);
     if ((rc = setup_lookahead(e, e.n_blk, e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
@@ -1927,7 +1927,7 @@ static int make_scratch(Engine& e, int device, int ld)
             e.n_cu = prop.multiProcessorCount;
     }
     int rc;
-    if ((rc = dev_alloc(e, &e.P, (size_t)3 * kNB * ld))) return rc;
+    if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * ld))) return rc;
     if ((rc = setup_lookahead(e, ld / kNB, ld))) return rc;
     if ((rc = dev_alloc(e, &e.dinv, (size_t)ld + kNB))) return rc;
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(ld / kNB + 1) * 4096))) return rc;
@@ -2196,7 +2196,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
 // HIP events, (0) rank-k update + partial-tile sum alone, (1) factorisation + triangular solves alone, (2) both back to
 // back on one stream (today's order), (3) both at once on two streams -- the factorisation on a valid S, the rank-k
 // update of the same Z writing its sum into a scratch matrix, so that only the sharing of the chip is measured, not a
-// dependency.  Dense elimination, one GPU.  ms[4] averages over reps.
+// dependency; (4) the factorisation's own duration inside (3).  Dense elimination, one GPU.  ms[5] averages over reps.
 int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
 {
     if (!h || !ms || reps <= 0) {
@@ -2238,9 +2238,9 @@ int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
         e.ctl_host->sync_timeout = 0;
         return hipMemcpy(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice);
     };
-    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+    double acc[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
     for (int r = 0; r < reps + 1 && err == hipSuccess; ++r) {   // repetition 0 is untimed
-        float t[4] = { 0.f, 0.f, 0.f, 0.f };
+        float t[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
         // (0) rank-k update + sum (leaves a valid S), (1) factorisation + solves
         if ((err = reset_flags()) != hipSuccess) break;
         (void)hipEventRecord(ev[0], e.stream);
@@ -2256,18 +2256,22 @@ int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
         if ((err = reset_flags()) != hipSuccess) break;
         launch_syrk_reduced(e);
         if ((err = hipStreamSynchronize(e.stream)) != hipSuccess) break;
+        // the factorisation is enqueued first: its workgroups (84 KB of LDS, one per CU) take their CUs, the rank-k
+        // update's (72 KB) fill what is left beside them
         (void)hipEventRecord(ev[0], e.stream);
         (void)hipStreamWaitEvent(sb, ev[0], 0);
+        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
+        (void)hipEventRecord(ev[3], e.stream);
         launch_syrk_plan(sb, e.ctl, e.Z, e.ldz, e.syrk);
         launch_reduce_plan(sb, e.ctl, e.syrk, e.ldz, e.n_pad + 1, S2);
         (void)hipEventRecord(ev[1], sb);
-        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
         (void)hipStreamWaitEvent(e.stream, ev[1], 0);
         (void)hipEventRecord(ev[2], e.stream);
         if ((err = hipEventSynchronize(ev[2])) != hipSuccess) break;
         (void)hipEventElapsedTime(&t[3], ev[0], ev[2]);
+        (void)hipEventElapsedTime(&t[4], ev[0], ev[3]);
         if (r > 0)
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 5; ++i)
                 acc[i] += t[i];
     }
     if (err == hipSuccess)
@@ -2280,7 +2284,7 @@ int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
         set_error(std::string("debug_overlap: ") + hipGetErrorString(err));
         return VMM_BA_ERR_HIP;
     }
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         ms[i] = acc[i] / reps;
     return VMM_BA_OK;
 }
