@@ -426,15 +426,19 @@ struct PairArgs {
 };
 
 #ifndef VMM_PAIR_NS
-#define VMM_PAIR_NS 4
+#define VMM_PAIR_NS 2
 #endif
 constexpr int kPairChunk = 128;   // left blocks staged per pass: 38 KB of LDS, four workgroups per CU
 constexpr int kPairSplit = VMM_PAIR_NS;                  // lanes that share one output column: each takes every
                                                          // kPairSplit-th term, the partial sums meet in a fixed shuffle tree
-constexpr int kPairsPerItem = 256 / (6 * kPairSplit);    // 6 x kPairSplit lanes per pair
+#ifndef VMM_PAIR_THREADS
+#define VMM_PAIR_THREADS 256
+#endif
+constexpr int kPairThreads = VMM_PAIR_THREADS;           // workgroup size of k_schur_pairs
+constexpr int kPairsPerItem = kPairThreads / (6 * kPairSplit);    // 6 x kPairSplit lanes per pair
 constexpr int kPairBlk = 38;      // doubles per staged block: 36 + 2, so that consecutive blocks start 12 banks apart
 
-__global__ __launch_bounds__(256) void k_schur_pairs(PairArgs a)
+__global__ __launch_bounds__(kPairThreads) void k_schur_pairs(PairArgs a)
 {
     if (a.ctl && a.ctl->done)
         return;
@@ -447,14 +451,14 @@ __global__ __launch_bounds__(256) void k_schur_pairs(PairArgs a)
         const int nb = gridDim.x - a.n_items, b = (int)blockIdx.x - a.n_items;
         for (int row = b; row <= n_pad; row += nb) {
             if (row == n_pad) {
-                for (int j = n_red + tid; j < n_pad; j += 256)
+                for (int j = n_red + tid; j < n_pad; j += kPairThreads)
                     a.S[(int64_t)n_pad * ld + j] = 0.0;
             } else if (row >= n_red) {
-                for (int j = tid; j < n_pad; j += 256)
+                for (int j = tid; j < n_pad; j += kPairThreads)
                     a.S[(int64_t)row * ld + j] = (a.add_diag && j == row) ? 1.0 : 0.0;
             } else {
                 const int c0 = 6 * (row / 6) + 6, c1 = min((row / 64) * 64 + 64, n_pad);
-                for (int j = c0 + tid; j < c1; j += 256)
+                for (int j = c0 + tid; j < c1; j += kPairThreads)
                     a.S[(int64_t)row * ld + j] = 0.0;
             }
         }
@@ -482,23 +486,23 @@ __global__ __launch_bounds__(256) void k_schur_pairs(PairArgs a)
         // stage the row's blocks lo .. hi-1: thread -> (block, pair of doubles).  All indices first, then all blocks:
         // two memory latencies per pass, not two per block.
         {
-            constexpr int NI = kPairChunk * 18 / 256;
+            constexpr int NI = (kPairChunk * 18 + kPairThreads - 1) / kPairThreads;
             int ie[NI];
             double2 v[NI];
 #pragma unroll
             for (int u = 0; u < NI; ++u) {
-                const int i = tid + 256 * u;
+                const int i = tid + kPairThreads * u;
                 const int k = min(i / 18, hi - lo - 1);
                 ie[u] = a.f2e[fs + lo + k];
             }
 #pragma unroll
             for (int u = 0; u < NI; ++u) {
-                const int i = tid + 256 * u;
+                const int i = tid + kPairThreads * u;
                 v[u] = *reinterpret_cast<const double2*>(Zc + 36 * (int64_t)ie[u] + 2 * (i % 18));
             }
 #pragma unroll
             for (int u = 0; u < NI; ++u) {
-                const int i = tid + 256 * u;
+                const int i = tid + kPairThreads * u;
                 if (i < (hi - lo) * 18)
                     *reinterpret_cast<double2*>(&As[kPairBlk * (i / 18) + 2 * (i % 18)]) = v[u];
             }
@@ -679,7 +683,7 @@ void launch_schur_rows(Engine& e, bool add_diag)
     a.da.alt_off = e.small_alt_off;
     a.add_diag = add_diag ? 1 : 0;
     const int n_fill = std::min(64, e.n_pad + 1);   // workgroups for the rows' zero fill and the padding
-    hipLaunchKernelGGL(k_schur_pairs, dim3(e.n_row_items + n_fill), dim3(256), 0, e.stream, a);
+    hipLaunchKernelGGL(k_schur_pairs, dim3(e.n_row_items + n_fill), dim3(kPairThreads), 0, e.stream, a);
 }
 
 void launch_syrk_only(Engine& e)

@@ -1078,19 +1078,17 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = build_order(e, e.ordE, e.n_e, own_e, own_f, p->obs_px, p->n_obs, &callerE, &startE, &otherE))) return fail(rc);
     if ((rc = build_order(e, e.ordF, e.n_f, own_f, own_e, p->obs_px, p->n_obs, &callerF, &startF))) return fail(rc);
 
-    // Fused evaluation (one evaluation per observation, lane = kept pose): worth it when most (e, f) pairs exist --
-    // a lane whose pair is not observed idles.  VMM_BA_EVAL=fused|twopass overrides.
+    // Fused evaluation (k_eval_fused: one evaluation per observation, lane = kept pose, both families' sums in
+    // registers).  Opt-in, VMM_BA_EVAL=fused: it needs ~370 registers per lane, so one wave per SIMD, and measured
+    // SLOWER than the two-pass kernel at two waves per SIMD (500 x 200: 59-68 us against 28.4; 2000 x 1000 f32:
+    // 291 against 308).
     {
         int n_act = 0;
         for (int q = 0; q < e.n_e; ++q)
             n_act += startE[q + 1] > startE[q];
-        e.fused_eval = n_act > 0 && (double)e.n_obs >= 0.6 * (double)n_act * (double)e.n_f;
-        if (const char* ev = getenv("VMM_BA_EVAL")) {
-            if (!strcmp(ev, "fused"))
-                e.fused_eval = n_act > 0;
-            else if (!strcmp(ev, "twopass"))
-                e.fused_eval = false;
-        }
+        e.fused_eval = false;
+        if (const char* ev = getenv("VMM_BA_EVAL"))
+            e.fused_eval = !strcmp(ev, "fused") && n_act > 0;
         if (e.fused_eval) {
             e.fused_n_e_act = n_act;
             e.fused_f_pad = round_up(e.n_f, 64);
