@@ -13,5 +13,5 @@ def test_no_instruction_touches_an_asm_load_destination_before_its_wait():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_chol_asm.py")], stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, universal_newlines=True)
     assert out.returncode == 0, out.stdout
-    assert "normal build: 32 asm loads" in out.stdout and "stamps build: 32 asm loads" in out.stdout
+    assert "normal build: 64 asm loads" in out.stdout and "stamps build: 64 asm loads" in out.stdout
     assert out.stdout.count("0 violations") == 2

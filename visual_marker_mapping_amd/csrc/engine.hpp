@@ -194,7 +194,7 @@ struct Engine {
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
     double* Ldiag = nullptr;        // [n_blk][64][64] Cholesky factors of the diagonal blocks
     double* Linv = nullptr;         // [n_blk][64][64] their inverses (all but the last block)
-    unsigned* flags = nullptr;      // [256] unused + [1] epoch word of the chained back-substitution
+    unsigned* flags = nullptr;      // [256] unused | epoch word | abort word | two tile counters of k_chol_step | agreement word
     unsigned long long* gran = nullptr;   // [2 * ld] {epoch, 32 value bits} granules of the chain's hand-offs
     bool no_chain = false;          // VMM_BA_NO_CHAIN=1: per-block back-substitution kernels
     unsigned long long* df_gran = nullptr;   // published 64x8 slices of the dataflow factorisation (<= 21 blocks)

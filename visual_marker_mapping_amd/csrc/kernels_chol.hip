@@ -387,36 +387,58 @@ typedef double double2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void update_tile_index(int n_blk, int k, int t, int& bi, int& bj)
 {
     // tile index -> (bi, bj): columns k+2..min(bi, n_blk-1) (block column k+1 is updated lazily by the
-    // panel of that column), rows k+2..n_blk
-    bi = k + 2;
-    bj = k + 2;
-    for (int r = k + 2; r <= n_blk; ++r) {
-        const int cnt = ((r < n_blk) ? r : n_blk - 1) - (k + 1);
-        if (t < cnt) {
-            bi = r;
-            bj = k + 2 + t;
-            return;
-        }
-        t -= cnt;
+    // panel of that column), rows k+2..n_blk.  Row q = bi - (k+2) holds q + 1 tiles, except the last row (the
+    // right-hand side, bi = n_blk), which has as many as the row before it: closed form, no search (a search
+    // from the first row costs ~50 cycles per row, 2 us at 94 rows -- as much as the tile's MFMAs).
+    const int n_rows = n_blk - (k + 2) + 1;                 // rows k+2 .. n_blk
+    const int before_last = (n_rows - 1) * n_rows / 2;      // tiles in front of the last row
+    int q;
+    if (t >= before_last) {
+        q = n_rows - 1;
+        t -= before_last;
+    } else {
+        q = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        // guard the rounding of the square root
+        while (q * (q + 1) / 2 > t)
+            --q;
+        while ((q + 1) * (q + 2) / 2 <= t)
+            ++q;
+        t -= q * (q + 1) / 2;
     }
+    bi = k + 2 + q;
+    bj = k + 2 + t;
 }
 
-// Workgroup u of n_wg takes the tiles u, u + n_wg, ...  With more tiles than compute units (large reduced
-// systems) the operands of the NEXT tile are requested before the MFMAs of the current one and parked in
-// the other half of the LDS, and the C tile is requested at the start of its own iteration and only added
-// after the 16 k-steps: a tile costs its MFMAs plus one barrier instead of a full memory latency.  No
-// register array lives across the loop back-edge (those end up in scratch).
-__device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, int n_blk, int k, int u, int n_wg,
+// The tiles of a launch's trailing update are handed out through a counter (one atomic per tile, fetched two tiles
+// ahead of its use): the dedicated update workgroups start at once, the panel workgroups of the same launch join when
+// their panel is stored -- at n = 6000 a panel takes ~26 us of a launch that lasts up to 150 us, and the 95 CUs of the
+// panel workgroups used to idle for the rest of it.  With more tiles than compute units the operands of the NEXT tile
+// are requested before the MFMAs of the current one and parked in the other half of the LDS, and the C tile is
+// requested at the start of its own iteration and only added after the 16 k-steps: a tile costs its MFMAs plus one
+// barrier instead of a full memory latency.  No register array lives across the loop back-edge (those end up in
+// scratch).  The order in which workgroups take tiles does not touch the result: a tile is updated by exactly one.
+__device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, int n_blk, int k, unsigned* counter,
                                                int n_tiles, const double* __restrict__ P, double* smem)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int fk = lane >> 4, fi = lane & 15;
-    if (u >= n_tiles)
+    // four ints in the padding columns of the first LDS row (the operand tiles use columns 0..63 of every row)
+    volatile int* slot = reinterpret_cast<volatile int*>(smem + 64);
+    if (tid == 0) {
+        slot[0] = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slot[1] = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    int t = slot[0], tn = slot[1];
+    const int u = t, n_wg = 0;   // (names the diagnostic stamps refer to)
+    (void)u;
+    (void)n_wg;
+    if (t >= n_tiles)
         return;
     int bi, bj;
-    update_tile_index(n_blk, k, u, bi, bj);
+    update_tile_index(n_blk, k, t, bi, bj);
     {
         double2 va[8], vb[8];
 #pragma unroll
@@ -436,10 +458,13 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
     }
     __syncthreads();
     int cur = 0;
-    for (int t = u; t < n_tiles; t += n_wg) {
+    for (int iter = 0;; ++iter) {
         const double* As = smem + cur * 128 * kLdsRow;
         const double* Bs = As + 64 * kLdsRow;
         const int I0 = bi * kNB, J0 = bj * kNB;
+        // the tile after the next one, read by everybody behind this iteration's closing barrier
+        if (tid == 0)
+            slot[2 + (iter & 1)] = (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // The requests of this tile's C values and of the NEXT tile's operands are issued as volatile asm:
         // written as plain loads, LLVM sinks them below the MFMA loop to their first use (measured: the
         // memory latency then adds to the MFMA time, 6.6 us per tile instead of ~3).  The results are only
@@ -454,21 +479,11 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     pc[8 * a + 4 * b + r] = S + (int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi;
-        const bool more = t + n_wg < n_tiles;   // workgroup-uniform
-        // next tile = n_wg positions further in the row-major list of lower tiles (rows only get longer, so
-        // this is a couple of steps; a search from the first row costs ~50 cycles per row: 2 us at 94 rows).
+        const bool more = tn < n_tiles;   // workgroup-uniform
         // The last tile re-requests itself (result unused).
         int nbi = bi, nbj = bj;
-        if (more) {
-            int off = bj - (k + 2) + n_wg;
-            int cnt = ((nbi < n_blk) ? nbi : n_blk - 1) - (k + 1);
-            while (off >= cnt) {
-                off -= cnt;
-                ++nbi;
-                cnt = ((nbi < n_blk) ? nbi : n_blk - 1) - (k + 1);
-            }
-            nbj = k + 2 + off;
-        }
+        if (more)
+            update_tile_index(n_blk, k, tn, nbi, nbj);
         double2v va[8], vb[8];
         const double* pa[8];
         const double* pb[8];
@@ -492,10 +507,12 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
         double b0 = Bs[fk * kLdsRow + wj * 32 + fi], b1 = Bs[fk * kLdsRow + wj * 32 + 16 + fi];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
+            // one pair of requests per k-step (issuing all 32 in the first four steps was measured slower: 4.02 against
+            // 3.69 ms per factorisation at n = 6000 -- the loop is bound by the memory system's throughput, not by latency)
             if (ks < 8) {   // this tile's C values (HBM, the longer latency) first ...
-                __asm__ volatile("global_load_dwordx2 %0, %1, off"
+                __asm__ volatile("global_load_dwordx2 %0, %1, off nt"
                                  : "=&v"(creg[(2 * ks) >> 3][((2 * ks) >> 2) & 1][(2 * ks) & 3]) : "v"(pc[2 * ks]) : "memory");
-                __asm__ volatile("global_load_dwordx2 %0, %1, off"
+                __asm__ volatile("global_load_dwordx2 %0, %1, off nt"
                                  : "=&v"(creg[(2 * ks + 1) >> 3][((2 * ks + 1) >> 2) & 1][(2 * ks + 1) & 3]) : "v"(pc[2 * ks + 1]) : "memory");
             } else {        // ... then the next tile's operands (L2)
                 __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[ks - 8]) : "v"(pa[ks - 8]) : "memory");
@@ -546,8 +563,11 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi]
-                        = creg[a][b][r] + acc[a][b][r];
+                    // non-temporal, like the loads of these values: a tile of C is touched once per launch, and kept out
+                    // of the L2 it leaves the transposed panel (3 MB, read by every workgroup for every tile) resident --
+                    // the update is bound by memory traffic (16 B of C + 16 B of operands per 128 flops), not by the MFMAs
+                    __builtin_nontemporal_store(creg[a][b][r] + acc[a][b][r],
+                                                &S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi]);
         USTAMP(44);
         // park the next tile's operands in the other half (nobody reads it during this iteration)
         double* An = smem + (cur ^ 1) * 128 * kLdsRow;
@@ -564,6 +584,10 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
         cur ^= 1;
         bi = nbi;
         bj = nbj;
+        t = tn;
+        tn = slot[2 + (iter & 1)];
+        if (t >= n_tiles)
+            break;
     }
 }
 
@@ -1605,7 +1629,7 @@ __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restric
                                                    int k, int n_panel, double* __restrict__ Pcur,
                                                    const double* __restrict__ Pprev, double* __restrict__ dinv,
                                                    double* __restrict__ Ld, double* __restrict__ Linv, int n_upd,
-                                                   int n_upd_wg)
+                                                   int n_upd_wg, unsigned* tile_ctr)
 {
     if (ctl->done)
         return;
@@ -1613,11 +1637,19 @@ __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restric
         phase_stamp(ctl, 3);
     if (ctl->lin_fail)
         return;
+    // the tile counter of launch k is word k & 1; launch k resets the other word for launch k + 1 (launch 0 has no
+    // trailing update and resets word 1: whatever an earlier factorisation left behind, word k & 1 is zero at launch k)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        tile_ctr[(k + 1) & 1] = 0u;
     __shared__ __attribute__((aligned(16))) double smem[kStepSmem];
-    if ((int)blockIdx.x < n_panel)
+    if ((int)blockIdx.x < n_panel) {
         chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, dinv, Ld, smem);
-    else if ((int)blockIdx.x < n_panel + n_upd_wg)
-        chol_update_wg(S, ld, n_blk, k - 1, (int)blockIdx.x - n_panel, n_upd_wg, n_upd, Pprev, smem);
+        if (n_upd > 0) {   // the panel is stored: help with the trailing update of panel k-1
+            __syncthreads();
+            chol_update_wg(S, ld, n_blk, k - 1, tile_ctr + (k & 1), n_upd, Pprev, smem);
+        }
+    } else if ((int)blockIdx.x < n_panel + n_upd_wg)
+        chol_update_wg(S, ld, n_blk, k - 1, tile_ctr + (k & 1), n_upd, Pprev, smem);
     else   // last workgroup of launches k >= 1: invert the diagonal factor of block k-1
         chol_inverse_wg(Ld + (int64_t)(k - 1) * 4096, dinv + (k - 1) * kNB, Linv + (int64_t)(k - 1) * 4096, smem);
 }
@@ -1684,7 +1716,7 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd_wg + (k > 0 ? 1 : 0)), dim3(256), 0, e.stream, ctl, S, ld,
                            n_pad, n_blk, k, n_panel, e.P2[k & 1],
                            k > 0 ? (const double*)e.P2[(k - 1) & 1] : (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
-                           n_upd, n_upd_wg);
+                           n_upd, n_upd_wg, e.flags + 258);
         if (getenv("VMM_BA_DEBUG")) {
             const hipError_t le = hipPeekAtLastError();
             if (le != hipSuccess)

@@ -501,7 +501,7 @@ static int do_allreduce(Engine& e, double* buf, size_t count)
 // sequences of collectives (graph or no graph: ADVICE.md round 2).
 static int rccl_agree(Engine& e, bool mine, bool* all)
 {
-    unsigned* word = e.flags + 258;
+    unsigned* word = e.flags + 260;
     const unsigned v = mine ? 1u : 0u;
     unsigned out = 0;
     HIP_TRY(hipMemcpyAsync(word, &v, sizeof(v), hipMemcpyHostToDevice, e.stream));
@@ -1330,7 +1330,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Linv, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
-    if ((rc = dev_alloc(e, &e.flags, 260))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.flags, 264))) return fail(rc);
     if ((rc = dev_alloc(e, &e.gran, (size_t)2 * e.ldz))) return fail(rc);
     if (!e.no_dataflow && dataflow_workgroups(e.n_blk) <= e.n_cu
         && (rc = dev_alloc(e, &e.df_gran, (size_t)e.n_blk * (e.n_blk + 1) / 2 * 8 * 1024)))
@@ -1932,7 +1932,7 @@ static int make_scratch(Engine& e, int device, int ld)
     if ((rc = dev_alloc(e, &e.dinv, (size_t)ld + kNB))) return rc;
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(ld / kNB + 1) * 4096))) return rc;
     if ((rc = dev_alloc(e, &e.Linv, (size_t)(ld / kNB + 1) * 4096))) return rc;
-    if ((rc = dev_alloc(e, &e.flags, 260))) return rc;
+    if ((rc = dev_alloc(e, &e.flags, 264))) return rc;
     if ((rc = dev_alloc(e, &e.gran, (size_t)2 * ld))) return rc;
     { const char* nc = getenv("VMM_BA_NO_CHAIN"); e.no_chain = nc && nc[0] == '1'; }
     { const char* nd = getenv("VMM_BA_NO_DATAFLOW"); e.no_dataflow = nd && nd[0] == '1'; }
