@@ -515,11 +515,16 @@ __global__ __launch_bounds__(kPairThreads) void k_schur_pairs(PairArgs a)
 #define VMM_PAIR_TB 4
 #endif
         constexpr int TB = VMM_PAIR_TB;
-        while (active && t < t1) {
-            int2 tt[TB];
+        // (the index pairs of the batch after this one are requested behind this batch's right operands, before its
+        // multiply-adds: one memory round trip per batch instead of two -- the waves of this kernel spend most of their
+        // life waiting, PMC SQ_WAIT_ANY 63 %)
+        int2 tt[TB];
+        if (active && t < t1) {
 #pragma unroll
             for (int u = 0; u < TB; ++u)
                 tt[u] = terms[min(t + u * kPairSplit, t1 - 1)];
+        }
+        while (active && t < t1) {
             double b[TB][6];
             bool ok[TB];
 #pragma unroll
@@ -540,6 +545,10 @@ __global__ __launch_bounds__(kPairThreads) void k_schur_pairs(PairArgs a)
                     }
                 }
             }
+            int2 tn[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+                tn[u] = terms[min(t + (TB + u) * kPairSplit, t1 - 1)];
             int n_ok = 0;
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
@@ -556,6 +565,9 @@ __global__ __launch_bounds__(kPairThreads) void k_schur_pairs(PairArgs a)
             t += n_ok * kPairSplit;
             if (n_ok < TB)
                 break;   // the rest of the list belongs to a later pass (or the list is finished)
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+                tt[u] = tn[u];
         }
     }
     // the kPairSplit partial sums of a column sit in neighbouring lanes: fixed tree

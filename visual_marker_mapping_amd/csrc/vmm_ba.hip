@@ -1194,9 +1194,9 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.ze, (size_t)6 * e.n_e))) return fail(rc);
     // Reduced-system formation: dense Z + MFMA rank-k update, or compressed Z + the pair-list kernel.  Both are
     // priced per launch from the block structure (measured at 500 x 200, profiles/r03_sparse_*: the dense update + its
-    // partial-tile sum take 118 us whatever the fill = 44 TFLOP/s; k_schur_pairs 19 us at 6-10 tags per image, 61 us at
-    // 25 % and 134 us at 50 % visibility = 18 us + 7.5 TFLOP/s of useful 6x6x6 block products); VMM_BA_SCHUR=dense|sparse
-    // overrides.
+    // partial-tile sum take 118 us whatever the fill = 44 TFLOP/s; k_schur_pairs 16 us at 6-10 tags per image, 57 us at
+    // 25 % and 116 us at 50 % visibility, priced as 18 us + 9 TFLOP/s of useful 6x6x6 block products);
+    // VMM_BA_SCHUR=dense|sparse overrides.
     {
         double pairs = 0.0;   // 6x6 block products of the lower triangle: sum over e of deg (deg + 1) / 2
         for (int q = 0; q < e.n_e; ++q) {
@@ -1205,7 +1205,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         }
         const double dense_flops = (double)(e.n_pad + 1) * (e.n_pad + 2) * e.k_dim;
         const double sparse_flops = 432.0 * pairs + 72.0 * (double)e.n_obs;
-        const double dense_us = dense_flops / 44e6 + 12.0, sparse_us = sparse_flops / 7.5e6 + 18.0;
+        const double dense_us = dense_flops / 44e6 + 12.0, sparse_us = sparse_flops / 9e6 + 18.0;
         e.sparse_schur = e.n_obs > 0 && sparse_us < dense_us;
         if (const char* sv = getenv("VMM_BA_SCHUR")) {
             if (!strcmp(sv, "dense"))
