@@ -1681,11 +1681,31 @@ static int update_tiles(int n_blk, int k)   // tiles of the trailing update of p
 
 int dataflow_workgroups(int n_blk) { return n_blk * (n_blk + 1) / 2 + n_blk; }
 
+// How many workgroups the one-launch factorisation may have.  Up to 48 block columns (1224 workgroups) -- more than the
+// chip holds at one per CU.  Workgroups are panel-major; a tile only waits for lower-numbered workgroups and for the
+// diagonal workgroup of its own column (fewer than n_blk + 1 <= n_cu numbers ahead), so with the in-order dispatch of
+// the hardware the lowest unfinished workgroup always has its producers resident or finished and the launch drains with
+// only a prefix resident.  HIP does not promise that order: the bounded spins and the redo of a pass that gave up
+// waiting (k_chol_step) make a wrong guess slow, not wrong.  Measured (MI355X, us per factorisation, this kernel vs one
+// k_chol_step launch per column): 24 blocks 328 vs 584, 30: 461 vs 744, 38: 701 vs 975, 47: 1097 vs 1232,
+// 60: 1948 vs 1711, 94: 6254 vs 3713 -- hence 48.  VMM_BA_DF_MAX_WG overrides the limit (experiments).
+int dataflow_max_workgroups(int n_cu)
+{
+    static const int env = [] {
+        const char* v = getenv("VMM_BA_DF_MAX_WG");
+        return v ? atoi(v) : 0;
+    }();
+    if (env > 0)
+        return env;
+    const int kMaxBlocks = 48;
+    return n_cu > kMaxBlocks ? std::max(n_cu, dataflow_workgroups(kMaxBlocks)) : n_cu;
+}
+
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl, bool safe)
 {
     const int n_blk = n_pad / kNB;
     const bool chain = n_blk <= e.n_cu && e.flags && e.gran && !e.no_chain && !safe;
-    if (chain && e.df_gran && !e.no_dataflow && dataflow_workgroups(n_blk) <= e.n_cu) {
+    if (chain && e.df_gran && !e.no_dataflow && dataflow_workgroups(n_blk) <= dataflow_max_workgroups(e.n_cu)) {
         // one launch for the factorisation + forward substitution, one for the back-substitution chain (which
         // bumps the epoch both kernels tag their granules with)
         DfArgs a;
