@@ -268,7 +268,7 @@ def main():
         # (tools/gpu_final.sh + tools/pmc_to_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # same command, gfx950 x2 read correction calibrated on k_cost's known 7.2 MB); traffic_source says so
         traffic = {}
-        tname = "r02_pmc_traffic.json"
+        tname = "r03_pmc_traffic.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if a.config == 2 and a.visibility == 1.0 and os.path.exists(tpath):
             with open(tpath) as f:
@@ -277,7 +277,7 @@ def main():
                        "schur_syrk": bpl.get("schur_syrk"),
                        "cholesky_solve": (bpl.get("chol_dataflow") or 0) + (bpl.get("backsolve_chain") or 0)}
         n_blk = (n_red + 63) // 64
-        dataflow = n_blk * (n_blk + 1) // 2 + n_blk <= 256
+        dataflow = n_blk <= 48          # dataflow_max_workgroups (csrc/kernels_chol.hip)
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
         names = {"cholesky_solve": ("k_chol_dataflow (one launch: %d workgroups, %d block columns) + k_backsolve_chain"

@@ -3,7 +3,7 @@ set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final gpurun_out/pmc
 export TMPDIR=/tmp
-timeout -k 10 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt
+timeout -k 10 1000 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/final/pytest_gpu.txt; cat gpurun_out/final/pytest_gpu.txt
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout -k 10 600 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err || exit 1
 cat gpurun_out/final/bench.json

@@ -11,7 +11,7 @@ import json
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc/pmc_summary.json"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_pmc_traffic.json"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_pmc_traffic.json"
 d = json.load(open(src))
 
 
