@@ -142,6 +142,7 @@ struct Engine {
     // when LmCtl::w_which is set); world > 1: 0 -- the all-reduced staging copy is copied into `small` on acceptance
     int64_t small_alt_off = 0;
     double *ev_H_cam = nullptr, *ev_H_tag = nullptr, *ev_g_cam = nullptr, *ev_g_tag = nullptr, *ev_cost = nullptr;
+    double* ev_pose_cost = nullptr;   // [n_e] behind the staging copy: per-pose costs of the evaluation (world > 1)
     double* W = nullptr;            // [36][ordE.n_pad]: J_e^T J_f per observation, E order (f64 precision)
     double* W2 = nullptr;           // second buffer: every LM iteration evaluates at the candidate, LmCtl::w_which says
                                     // which one belongs to x
@@ -204,7 +205,7 @@ struct Engine {
     uint32_t dbg_spin_df = 0, dbg_spin_chain = 0;
     bool dbg_spin_once = false;
     double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)
-    double* step_comm = nullptr;    // [6*n_e + 2]: delta of the eliminated family | cross term
+    double* step_comm = nullptr;    // [7*n_e + 1]: delta of the eliminated family | per-pose cross terms | votes
     double* cost_comm = nullptr;    // [2] candidate cost (all-reduced)
     double* part_cost = nullptr;    // [ordE.n_tasks]
     double* part_cross = nullptr;   // [ordE.n_tasks] cross-term wave partials
@@ -267,7 +268,6 @@ void launch_schur_rows(Engine& e, bool add_diag);   // block-sparse: S from the 
 int schur_pairs_per_item();                           // pairs of one row a workgroup of k_schur_pairs takes
 void launch_syrk_only(Engine& e);
 void launch_syrk_reduced(Engine& e);
-void launch_add_diag(Engine& e);
 void launch_pack_lower(Engine& e, bool unpack);
 void launch_syrk_plan(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, const SyrkPlan& p);
 void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int ld, int n_rows, double* S);

@@ -828,7 +828,8 @@ void launch_eval_passes(Engine& e, int robustify, double huber_a, bool use_ctl)
     rE.part = e.ordE.part;
     rE.Hout = e_is_cam ? oH_cam : oH_tag;
     rE.gout = e_is_cam ? og_cam : og_tag;
-    rE.pose_cost = e.part_cost;   // per-pose cost of the eliminated family
+    // per-pose cost of the eliminated family; an LM evaluation with world > 1 leaves it in the all-reduced staging buffer
+    rE.pose_cost = (lm && e.multi) ? e.ev_pose_cost : e.part_cost;
     const bool want_gm = lm && !e.multi;   // world > 1: the gradient is only complete behind the all-reduce
     rE.pose7 = want_gm ? (e_is_cam ? e.cam_cand : e.tag_cand) : nullptr;
     rE.euclid = (e.points && !e_is_cam) ? 1 : 0;
@@ -858,9 +859,9 @@ void launch_eval_passes(Engine& e, int robustify, double huber_a, bool use_ctl)
     rF.pose_cost = nullptr;
     hipLaunchKernelGGL(k_reduce_pose, dim3(((e.n_e + e.n_f) * 32 + 255) / 256), dim3(256), 0, e.stream, ctl, rE, rF,
                        (lm && !e.multi) ? e.small_alt_off : (int64_t)0);
-    if (e.multi || !use_ctl)   // single-GPU solves sum the pose costs in k_control
+    if (!lm)   // LM evaluations: k_control sums the per-pose costs
         hipLaunchKernelGGL(k_sum, dim3(1), dim3(256), 0, e.stream, ctl, e.part_cost, e.n_e, 1,
-                           lm ? e.ev_cost : e.cost_slot);
+                           e.cost_slot);
 }
 
 void launch_sum(Engine& e, bool guard, const double* in, int n, double* out)

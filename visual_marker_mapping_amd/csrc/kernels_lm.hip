@@ -124,11 +124,9 @@ extern "C" int vmm_ba_debug_read_ctl_stamps(unsigned long long* out)
 
 struct DecideArgs {
     const double* pose_part;        // [n_pose][5], k_backsub / k_candidate
-    const double* cross_slot;       // world > 1: all-reduced cross term
-    const double* cross_parts;      // one GPU: its per-pose partials, summed here in pose order
+    const double* cross_parts;      // per-pose partials of the cross term (world > 1: all-reduced), summed here in pose order
     int n_cross;
-    const double* cand_cost_slot;   // world > 1: cost slot of the all-reduced staging copy
-    const double* cost_parts;       // one GPU: per-pose costs of the evaluation at the candidate
+    const double* cost_parts;       // per-pose costs of the evaluation at the candidate (world > 1: all-reduced)
     int n_cost;
     const double* pose_gm;          // one GPU: per-pose |Plus(x+, -g) - x+|_inf from k_reduce_pose; null: computed here
 };
@@ -208,14 +206,13 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
             }
         }
     }
-    // one GPU: the per-pose partials of the cross term and the per-pose costs of the evaluation at the candidate are
-    // summed here (pose order); world > 1: they were summed and all-reduced before (scalar slots)
-    if (dz.cross_parts && !first)
+    // the per-pose partials of the cross term (world > 1: all-reduced) are summed here in pose order; so are, on one
+    // GPU, the per-pose costs of the evaluation at the candidate (world > 1: an all-reduced scalar slot)
+    if (!first)
         for (int i = tid; i < dz.n_cross; i += (int)blockDim.x)
             cross += dz.cross_parts[i];
-    if (dz.cost_parts)
-        for (int i = tid; i < dz.n_cost; i += (int)blockDim.x)
-            ccost += dz.cost_parts[i];
+    for (int i = tid; i < dz.n_cost; i += (int)blockDim.x)
+        ccost += dz.cost_parts[i];
     CTL_RT(1);
     double red[8] = { gd, quad, sn, xn, cross, ccost, xn0, 0.0 };
     double redm[2] = { bad, gm };
@@ -227,8 +224,8 @@ __global__ __launch_bounds__(1024) void k_control(LmCtl* ctl, PoseViews pv, cons
         quad = red[1];
         sn = red[2];
         xn = red[3];
-        cross = dz.cross_parts ? red[4] : dz.cross_slot[0];
-        ccost = dz.cost_parts ? red[5] : dz.cand_cost_slot[0];
+        cross = red[4];
+        ccost = red[5];
         xn0 = red[6];
         bad = redm[0];
         gm = redm[1];
@@ -493,9 +490,9 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
                                                  const int32_t* __restrict__ e_other)
 {
     // world > 1: this rank's vote on "the factorisation of this pass gave up waiting" rides on the step all-reduce
-    // (slot 6 n_e + 1; slot 6 n_e is the cross term), so that all ranks pause in the same pass (k_candidate)
+    // (slot 7 n_e, behind the steps and the per-pose cross terms), so that all ranks pause in the same pass (k_candidate)
     if (!FUSE && blockIdx.x == 0 && threadIdx.x == 0)
-        step_comm[6 * (int64_t)n_e + 1] = (ctl->done == 2) ? 1.0 : 0.0;
+        step_comm[7 * (int64_t)n_e] = (ctl->done == 2) ? 1.0 : 0.0;
     if (ctl->done)
         return;
     phase_stamp(ctl, 4);
@@ -612,7 +609,7 @@ __global__ void k_candidate(LmCtl* ctl, PoseViews pv, int n_e, int e_off_pose, i
 {
     // the summed votes of k_backsub: some rank's factorisation gave up waiting in this pass -> every rank pauses here
     // (the ranks must take the same decisions and make the same collective calls; the hosts redo the pass together)
-    const bool remote = step_comm[6 * (int64_t)n_e + 1] > 0.0;
+    const bool remote = step_comm[7 * (int64_t)n_e] > 0.0;
     if (remote && blockIdx.x == 0 && threadIdx.x == 0 && ctl->done != 1) {
         if (ctl->done == 0)
             atomicOr(&ctl->sync_timeout, 4);
@@ -722,13 +719,12 @@ void launch_control(Engine& e)
     const bool single = !e.multi;
     DecideArgs dz;
     dz.pose_part = e.pose_part;
-    dz.cross_slot = e.step_comm + 6 * (size_t)e.n_e;
-    dz.cross_parts = single ? e.part_cross : (const double*)nullptr;
+    // world > 1: k_backsub leaves its per-pose cross terms behind the steps in the all-reduced buffer
+    dz.cross_parts = single ? e.part_cross : e.step_comm + 6 * (size_t)e.n_e;
     dz.n_cross = e.n_e;
-    // candidate cost: one GPU -- the per-pose costs of the evaluation at the candidate, summed in pose order;
-    // world > 1 -- the cost slot of the all-reduced staging copy
-    dz.cand_cost_slot = e.ev_cost;
-    dz.cost_parts = single ? e.part_cost : (const double*)nullptr;
+    // candidate cost: the per-pose costs of the evaluation at the candidate (world > 1: all-reduced behind the staging
+    // copy), summed in pose order
+    dz.cost_parts = single ? e.part_cost : e.ev_pose_cost;
     dz.n_cost = e.n_e;
     dz.pose_gm = single ? e.pose_gm : (const double*)nullptr;
     // one GPU: nothing to copy (src == dst), the accepted evaluation's blocks are selected through w_which;
@@ -745,9 +741,11 @@ void launch_backsub(Engine& e)
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const int nb_e = e.n_e;   // one workgroup per eliminated pose
     const double* const Zp = e.sparse_schur ? e.Zc : e.Z;
+    // world > 1: the per-pose cross terms travel with the steps (one all-reduce, summed over the poses by k_control)
+    double* const crossp = e.multi ? e.step_comm + 6 * (size_t)e.n_e : e.part_cross;
 #define VMM_BACKSUB(FUSE, SP, GRID)                                                                                      \
     hipLaunchKernelGGL((k_backsub<FUSE, SP>), dim3(GRID), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,   \
-                       Zp, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, e.part_cross, views(e), f_off, e.n_f,  \
+                       Zp, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, crossp, views(e), f_off, e.n_f,        \
                        nb_e, e.delta, e.H_cam, e.g_cam, e.small_alt_off, e.active, e.pose_part,                           \
                        (const int32_t*)e.ordE.start, (const int32_t*)e.ordE.other)
     if (e.multi) {

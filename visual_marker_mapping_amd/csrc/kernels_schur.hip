@@ -307,7 +307,8 @@ struct DiagArgs {        // kept family's damped diagonal blocks and rhs, added 
 // workgroups keep every CU's memory pipe busy (four per tile left the launch at 3.7 TB/s).
 template <bool ADD_DIAG>
 __global__ __launch_bounds__(256) void k_reduce_partials(const LmCtl* ctl, SyrkPlanDev pl, int ld, int n_rows,
-                                                         double* __restrict__ S, DiagArgs da)
+                                                         double* __restrict__ S, DiagArgs da,
+                                                         double* __restrict__ packed = nullptr)
 {
     if (ctl && ctl->done)
         return;
@@ -360,38 +361,19 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const LmCtl* ctl, SyrkP
             }
             out[h] = v;
         }
-        *reinterpret_cast<double2*>(S + (int64_t)row * ld + J0 + tc) = make_double2(out[0], out[1]);
-    }
-}
-
-// Adds the kept family's damped diagonal blocks and right-hand side (identical on every rank, so with
-// world > 1 it runs after the all-reduce): S_ff += s H_f s + D_f^2, padded diagonal = 1, rhs row += s_f g_f.
-__global__ void k_add_diag(const LmCtl* ctl, int n_f, int f_off_pose, const double* __restrict__ H_F,
-                           const double* __restrict__ g_F, const double* __restrict__ scale,
-                           const double* __restrict__ D2, double* __restrict__ S, int ld, int n_red,
-                           int n_pad)
-{
-    if (ctl && ctl->done)
-        return;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < 36 * n_f) {
-        const int f = tid / 36, a = (tid % 36) / 6, b = tid % 6;
-        if (b <= a) {
-            const double* s = scale + 6 * (int64_t)(f_off_pose + f);
-            double v = s[a] * H_F[36 * (int64_t)f + 6 * a + b] * s[b];
-            if (a == b)
-                v += D2[6 * (int64_t)(f_off_pose + f) + a];
-            S[(int64_t)(6 * f + a) * ld + 6 * f + b] += v;
+        if (!ADD_DIAG && packed) {
+            // world > 1: straight into the packed lower triangle that travels through the all-reduce (k_pack_lower's
+            // layout: row r holds its r + 1 leading entries)
+            const int64_t base = (int64_t)row * (row + 1) / 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (J0 + tc + h <= row)
+                    packed[base + J0 + tc + h] = out[h];
+        } else {
+            *reinterpret_cast<double2*>(S + (int64_t)row * ld + J0 + tc) = make_double2(out[0], out[1]);
         }
-        if (b == 0)
-            S[(int64_t)n_pad * ld + 6 * f + a] += scale[6 * (int64_t)(f_off_pose + f) + a] * g_F[6 * (int64_t)f + a];
-    } else {
-        const int i = n_red + (tid - 36 * n_f);
-        if (i < n_pad)
-            S[(int64_t)i * ld + i] = 1.0;
     }
 }
-
 
 // ---- block-sparse reduced system: S(f, f') -= sum over the eliminated poses e that see both f and f' --------------
 //
@@ -446,7 +428,7 @@ __global__ __launch_bounds__(kPairThreads) void k_schur_pairs(PairArgs a)
     const int n_red = a.da.n_red, n_pad = a.da.n_pad, ld = a.ld;
     if ((int)blockIdx.x >= a.n_items) {
         // what no pair writes: the rest of every row's diagonal 64-block (the Cholesky kernels load whole 16x16 tiles
-        // of it) and the padding of the reduced system (unit rows on one GPU; world > 1: zero, k_add_diag sets the ones
+        // of it) and the padding of the reduced system (unit rows on one GPU; world > 1: zero, k_unpack_diag sets the ones
         // behind the all-reduce)
         const int nb = gridDim.x - a.n_items, b = (int)blockIdx.x - a.n_items;
         for (int row = b; row <= n_pad; row += nb) {
@@ -707,14 +689,17 @@ void launch_syrk_only(Engine& e)
 }
 
 // S = -(sum of partials) [+ damped diagonal blocks and rhs on one GPU; with world > 1 they are added by
-// launch_add_diag after the all-reduce, being identical on every rank]
+// k_unpack_diag after the all-reduce, being identical on every rank]
 void launch_syrk_reduced(Engine& e)
 {
     launch_syrk_only(e);
     if (e.sparse_schur)
         return;   // k_schur_rows writes S itself (with the diagonal blocks on one GPU)
     if (e.multi) {
-        launch_reduce_plan(e.stream, e.ctl, e.syrk, e.ldz, e.n_pad + 1, e.S);
+        DiagArgs none = {};
+        if (e.syrk.n_tiles > 0)
+            hipLaunchKernelGGL((k_reduce_partials<false>), dim3(16 * e.syrk.n_tiles), dim3(256), 0, e.stream, e.ctl,
+                               plan_dev(e.syrk), e.ldz, e.n_pad + 1, e.S, none, e.S_packed);
         return;
     }
     const int f_off = e.elim_cams ? e.n_cams : 0;
@@ -749,25 +734,60 @@ __global__ __launch_bounds__(256) void k_pack_lower(const LmCtl* ctl, const doub
     }
 }
 
+// Behind the all-reduce: row r of the packed triangle back into S, plus what is identical on every rank and therefore
+// not part of the sum: the kept family's damped diagonal blocks S_ff += s H_f s + D_f^2, the right-hand side row
+// += s_f g_f, and the unit diagonal of the padding.
+__global__ __launch_bounds__(256) void k_unpack_diag(const LmCtl* ctl, const double* __restrict__ packed, int ld,
+                                                     int f_off_pose, const double* __restrict__ H_F,
+                                                     const double* __restrict__ g_F, const double* __restrict__ scale,
+                                                     const double* __restrict__ D2, double* __restrict__ S, int n_red,
+                                                     int n_pad)
+{
+    if (ctl && ctl->done)
+        return;
+    const int r = blockIdx.x;
+    const int64_t base = (int64_t)r * (r + 1) / 2;
+    const double* sF = scale + 6 * (int64_t)f_off_pose;
+    const double* dF = D2 + 6 * (int64_t)f_off_pose;
+    for (int c = threadIdx.x; c <= r; c += 256) {
+        double v = packed[base + c];
+        if (r == n_pad) {
+            if (c < n_red)
+                v += sF[c] * g_F[c];
+        } else if (r < n_red) {
+            if (c / 6 == r / 6) {
+                double add = sF[r] * H_F[36 * (int64_t)(r / 6) + 6 * (r % 6) + c % 6] * sF[c];
+                if (c == r)
+                    add += dF[r];
+                v += add;
+            }
+        } else if (c == r) {
+            v = 1.0;
+        }
+        S[(int64_t)r * ld + c] = v;
+    }
+}
+
+// World > 1, in front of the all-reduce.  The dense rank-k path packs in its reduction kernel (launch_syrk_reduced);
+// only the block-sparse path, whose kernel writes S itself, needs the copy.
 void launch_pack_lower(Engine& e, bool unpack)
 {
     if (!e.multi)
         return;
-    hipLaunchKernelGGL(k_pack_lower, dim3(e.n_pad + 1), dim3(256), 0, e.stream, (const LmCtl*)e.ctl, (const double*)e.S,
-                       e.ldz, e.n_pad + 1, e.S_packed, unpack, e.S);
-}
-
-void launch_add_diag(Engine& e)
-{
-    if (!e.multi)
-        return;   // folded into the slab reduction
+    if (!unpack) {
+        if (e.sparse_schur)
+            hipLaunchKernelGGL(k_pack_lower, dim3(e.n_pad + 1), dim3(256), 0, e.stream, (const LmCtl*)e.ctl,
+                               (const double*)e.S, e.ldz, e.n_pad + 1, e.S_packed, false, e.S);
+        return;
+    }
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const double* H_F = e.elim_cams ? e.H_tag : e.H_cam;
     const double* g_F = e.elim_cams ? e.g_tag : e.g_cam;
-    const int threads = 36 * e.n_f + (e.n_pad - e.n_red);
-    hipLaunchKernelGGL(k_add_diag, dim3((threads + 255) / 256), dim3(256), 0, e.stream, e.ctl, e.n_f, f_off, H_F, g_F,
-                       e.scale, e.D2, e.S, e.ldz, e.n_red, e.n_pad);
+    hipLaunchKernelGGL(k_unpack_diag, dim3(e.n_pad + 1), dim3(256), 0, e.stream, (const LmCtl*)e.ctl,
+                       (const double*)e.S_packed, e.ldz, f_off, H_F, g_F, (const double*)e.scale, (const double*)e.D2,
+                       e.S, e.n_red, e.n_pad);
 }
+
 
 // Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources
 // are known before any launch is recorded into a hipGraph (nothing may be loaded lazily under stream capture).
@@ -783,7 +803,7 @@ int preload_schur_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_syrk_streamk)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<false>)) != hipSuccess;
-    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_add_diag)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_unpack_diag)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_pack_lower)) != hipSuccess;
     return bad;
 }

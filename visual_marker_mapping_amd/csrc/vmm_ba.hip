@@ -572,12 +572,9 @@ static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg, bool re
         launch_pack_lower(e, false);
         break;
     case 2:
-        launch_pack_lower(e, true);
-        launch_add_diag(e);
+        launch_pack_lower(e, true);   // world > 1: unpack + the kept family's diagonal blocks
         launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl, redo);
         launch_backsub(e);
-        if (e.multi)
-            launch_sum(e, true, e.part_cross, e.n_e, e.step_comm + 6 * (size_t)e.n_e);
         break;
     default:
         launch_candidate(e);   // world > 1 only; one GPU forms the candidates in k_backsub
@@ -589,9 +586,9 @@ static void enqueue_segment(Engine& e, const vmm_ba_options& o, int seg, bool re
 static int allreduce_after(Engine& e, int seg)
 {
     switch (seg) {
-    case 0: return do_allreduce(e, e.small_stage, e.small_count);   // blocks, gradient and cost at the candidate
+    case 0: return do_allreduce(e, e.small_stage, e.small_count + (size_t)e.n_e);   // blocks, gradient, per-pose costs at the candidate
     case 1: return do_allreduce(e, e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2);
-    case 2: return do_allreduce(e, e.step_comm, 6 * (size_t)e.n_e + 2);   // step | cross term | sync-time-out votes
+    case 2: return do_allreduce(e, e.step_comm, 7 * (size_t)e.n_e + 1);   // steps | per-pose cross terms | sync-time-out votes
     default: return VMM_BA_OK;
     }
 }
@@ -1149,7 +1146,9 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     e.cost_slot = e.g_tag + (size_t)6 * e.n_tags;
     // the LM loop evaluates at the candidate into this staging copy (all-reduced when world > 1); it replaces the
     // working copy when the step is accepted
-    if ((rc = dev_alloc(e, &e.small_stage, e.small_count))) return fail(rc);
+    // (+ n_e per-pose costs of the eliminated family behind it: world > 1 sums them over the ranks with the blocks)
+    if ((rc = dev_alloc(e, &e.small_stage, e.small_count + (size_t)e.n_e))) return fail(rc);
+    e.ev_pose_cost = e.small_stage + e.small_count;
     e.small_alt_off = e.multi ? 0 : (int64_t)(e.small_stage - e.small);
     e.ev_H_cam = e.small_stage;
     e.ev_H_tag = e.ev_H_cam + (size_t)36 * e.n_cams;
@@ -1336,7 +1335,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         && (rc = dev_alloc(e, &e.df_gran, (size_t)e.n_blk * (e.n_blk + 1) / 2 * 8 * 1024)))
         return fail(rc);
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
-    if ((rc = dev_alloc(e, &e.step_comm, (size_t)6 * e.n_e + 2))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.step_comm, (size_t)7 * e.n_e + 1))) return fail(rc);
     if ((rc = dev_alloc(e, &e.cost_comm, 2))) return fail(rc);
     const size_t n_part = (size_t)std::max<int>(e.ordE.n_tasks, e.n_e) + 1;
     if ((rc = dev_alloc(e, &e.part_cost, n_part))) return fail(rc);
@@ -2163,7 +2162,8 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     if ((rc = timed([&] { launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl); },
                     [&] {
                         launch_syrk_reduced(e);
-                        launch_add_diag(e);
+                        launch_pack_lower(e, false);   // world > 1: this rank's share alone (no all-reduce here)
+                        launch_pack_lower(e, true);
                     },
                     &out->cholesky_ms)))
         return rc;
