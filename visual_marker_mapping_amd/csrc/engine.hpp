@@ -190,8 +190,8 @@ struct Engine {
     SyrkPlan syrk;                  // stream-K plan of S = Z^T Z
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
     double* S_packed = nullptr;     // world > 1: rows 0..n_pad of the lower triangle, packed, for the all-reduce
-    double* P = nullptr;            // [2][kNB][ldz] transposed Cholesky panels (alternating)
-    double* P2[2] = { nullptr, nullptr };
+    double* P = nullptr;            // [4][kNB][ldz] transposed Cholesky panels (ring: panel k in slot k & 3)
+    double* P4[4] = { nullptr, nullptr, nullptr, nullptr };
     double* dinv = nullptr;         // [ldz] reciprocals of the Cholesky diagonal
     double* Ldiag = nullptr;        // [n_blk][64][64] Cholesky factors of the diagonal blocks
     double* Linv = nullptr;         // [n_blk][64][64] their inverses (all but the last block)

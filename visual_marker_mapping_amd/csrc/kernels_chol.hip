@@ -239,8 +239,9 @@ __device__ __forceinline__ void panel_round(const int w, const int lane,
 template <bool HAS_T>
 __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
                                            double* __restrict__ P, const double* __restrict__ Pprev,
-                                           double* __restrict__ dinv, double* __restrict__ Ld, double* RA,
-                                           double* Pd, double* Pt, double* invd, double* Ads, double* Ats)
+                                           const double* __restrict__ Pprev2, double* __restrict__ dinv,
+                                           double* __restrict__ Ld, double* RA, double* Pd, double* Pt, double* invd,
+                                           double* Ads, double* Ats)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -268,20 +269,27 @@ __device__ __forceinline__ void panel_body(LmCtl* ctl, double* __restrict__ S, i
             }
         }
     }
-    // Look-ahead: the trailing update of panel k-1 skips block column k (k_chol_update starts at column
-    // k+1 of ITS panel), so this kernel does not have to wait for it; the missing rank-64 update of the
-    // tiles (k,k) and (i,k) is applied here from the previous transposed panel Pprev (64 x ld).
+    // Look-ahead: the trailing updates skip this block column (chol_update2_wg starts one or two columns further), so
+    // this kernel does not have to wait for them; the missing rank-64 updates of the tiles (k,k) and (i,k) are applied
+    // here from the transposed panels that are still pending: Pprev2 (block column k-2; even k only, the pair of
+    // panels k-2, k-1 is applied to the rest of the matrix by this launch and the next) and Pprev (k-1).
     STAMP(6);
-    if (Pprev) {
-        // stage Pprev[:, K0..K0+63] (diagonal rows; also the B operand) and Pprev[:, R0..R0+63] k-major
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const double* __restrict__ Pq = pp == 0 ? Pprev2 : Pprev;
+        if (!Pq)
+            continue;
+        if (pp == 1 && Pprev2)
+            __syncthreads();   // the first panel's operands are consumed
+        // stage Pq[:, K0..K0+63] (diagonal rows; also the B operand) and Pq[:, R0..R0+63] k-major
         double2 va[8], vt[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int idx = it * 256 + tid;
             const int mm = idx >> 5, c = (idx & 31) * 2;
-            va[it] = *reinterpret_cast<const double2*>(Pprev + (int64_t)mm * ld + K0 + c);
+            va[it] = *reinterpret_cast<const double2*>(Pq + (int64_t)mm * ld + K0 + c);
             if (HAS_T)
-                vt[it] = *reinterpret_cast<const double2*>(Pprev + (int64_t)mm * ld + R0 + c);
+                vt[it] = *reinterpret_cast<const double2*>(Pq + (int64_t)mm * ld + R0 + c);
         }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -356,7 +364,8 @@ constexpr int kStepSmem = kPanelSmem > kUpdateSmem ? kPanelSmem : kUpdateSmem;
 
 __device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int k,
                                               double* __restrict__ P, const double* __restrict__ Pprev,
-                                              double* __restrict__ dinv, double* __restrict__ Ld, double* smem)
+                                              const double* __restrict__ Pprev2, double* __restrict__ dinv,
+                                              double* __restrict__ Ld, double* smem)
 {
     double* RA = smem;                     // workgroup 0: L^T (stride kLdT); others: result tile R (stride kLd)
     double* Pd = RA + 64 * kLdT;
@@ -365,9 +374,9 @@ __device__ __forceinline__ void chol_panel_wg(LmCtl* ctl, double* __restrict__ S
     double* Ads = invd + 64;               // previous panel, diagonal rows (k-major); 16-byte aligned offsets
     double* Ats = Ads + 64 * kLdsRow;      // previous panel, this workgroup's rows
     if (blockIdx.x == 0)
-        panel_body<false>(ctl, S, ld, n_pad, k, P, Pprev, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
+        panel_body<false>(ctl, S, ld, n_pad, k, P, Pprev, Pprev2, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
     else
-        panel_body<true>(ctl, S, ld, n_pad, k, P, Pprev, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
+        panel_body<true>(ctl, S, ld, n_pad, k, P, Pprev, Pprev2, dinv, Ld, RA, Pd, Pt, invd, Ads, Ats);
 }
 
 #ifdef VMM_STAMPS
@@ -587,6 +596,237 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
         t = tn;
         tn = slot[2 + (iter & 1)];
         if (t >= n_tiles)
+            break;
+    }
+}
+
+// Rank-128 trailing update: the transposed panels PA (block column c0-3) and PB (c0-2) applied in ONE visit of each C tile
+// of the block columns >= c0 (rows >= column, the right-hand side row included).  A rank-64 visit moves 16 B of C per
+// 128 flops and the launch is bound by that traffic (measured at n = 6000: the MFMA work of two updates in one visit
+// costs 1.35x one visit, not 2x); the pair halves it.  Tile t of the pair's list: first block column c0 (needed by the
+// next panel), then the triangle of the columns > c0 in update_tile_index order; the list is worked off by two
+// consecutive launches (tiles [t0, t1) each, handed out by `counter` as in chol_update_wg).
+// One loop iteration = one tile = two halves of 16 k-steps: half 0 multiplies the PA operands (parked in LDS half `0`)
+// while the tile's C values (non-temporal) and its PB operands are requested, half 1 multiplies the PB operands
+// (LDS half `1`) while the NEXT tile's PA operands are requested; C is added and stored behind half 1.  As in
+// chol_update_wg the requests are volatile asm, touched only behind the matching s_waitcnt (tools/check_chol_asm.py).
+__device__ __forceinline__ void pair_tile_index(int n_blk, int c0, int t, int& bi, int& bj)
+{
+    const int n_first = n_blk - c0 + 1;   // block column c0: rows c0 .. n_blk
+    if (t < n_first) {
+        bi = c0 + t;
+        bj = c0;
+    } else {
+        update_tile_index(n_blk, c0 - 1, t - n_first, bi, bj);
+    }
+}
+
+__device__ __forceinline__ void chol_update2_wg(double* __restrict__ S, int ld, int n_blk, int c0, unsigned* counter,
+                                                int t0, int t1, const double* __restrict__ PA,
+                                                const double* __restrict__ PB, double* smem)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int fk = lane >> 4, fi = lane & 15;
+    volatile int* slot = reinterpret_cast<volatile int*>(smem + 64);   // padding columns of the first LDS row
+    if (tid == 0) {
+        slot[0] = t0 + (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slot[1] = t0 + (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    int t = slot[0], tn = slot[1];
+    if (t >= t1)
+        return;
+    int bi, bj;
+    pair_tile_index(n_blk, c0, t, bi, bj);
+    double* const L0 = smem;                    // PA operands: A rows 0..63, B rows 64..127 (k-major)
+    double* const L1 = smem + 128 * kLdsRow;    // PB operands
+    {
+        double2 va[8], vb[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            va[it] = *reinterpret_cast<const double2*>(PA + (int64_t)m * ld + bi * kNB + c);
+            vb[it] = *reinterpret_cast<const double2*>(PA + (int64_t)m * ld + bj * kNB + c);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            *reinterpret_cast<double2*>(&L0[m * kLdsRow + c]) = va[it];
+            *reinterpret_cast<double2*>(&L0[(64 + m) * kLdsRow + c]) = vb[it];
+        }
+    }
+    __syncthreads();
+    for (int iter = 0;; ++iter) {
+        const int I0 = bi * kNB, J0 = bj * kNB;
+        if (tid == 0)   // the tile after the next one, read by everybody behind this iteration's closing barrier
+            slot[2 + (iter & 1)] = t0 + (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double creg[2][2][4];
+        const double* pc[16];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pc[8 * a + 4 * b + r] = S + (int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi;
+        double2v va[8], vb[8];
+        const double* pa[8];
+        const double* pb[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            pa[it] = PB + (int64_t)m * ld + bi * kNB + c;
+            pb[it] = PB + (int64_t)m * ld + bj * kNB + c;
+        }
+        double4_t acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+        // ---- half 0: PA operands; requests: this tile's C values, then its PB operands
+        {
+            const double* As = L0;
+            const double* Bs = L0 + 64 * kLdsRow;
+            double a0 = -As[fk * kLdsRow + wi * 32 + fi], a1 = -As[fk * kLdsRow + wi * 32 + 16 + fi];
+            double b0 = Bs[fk * kLdsRow + wj * 32 + fi], b1 = Bs[fk * kLdsRow + wj * 32 + 16 + fi];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks < 8) {
+                    __asm__ volatile("global_load_dwordx2 %0, %1, off nt"
+                                     : "=&v"(creg[(2 * ks) >> 3][((2 * ks) >> 2) & 1][(2 * ks) & 3]) : "v"(pc[2 * ks]) : "memory");
+                    __asm__ volatile("global_load_dwordx2 %0, %1, off nt"
+                                     : "=&v"(creg[(2 * ks + 1) >> 3][((2 * ks + 1) >> 2) & 1][(2 * ks + 1) & 3]) : "v"(pc[2 * ks + 1]) : "memory");
+                } else {
+                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[ks - 8]) : "v"(pa[ks - 8]) : "memory");
+                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[ks - 8]) : "v"(pb[ks - 8]) : "memory");
+                }
+                double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
+                if (ks < 15) {
+                    const int row = ((ks + 1) * 4 + fk) * kLdsRow;
+                    na0 = -As[row + wi * 32 + fi];
+                    na1 = -As[row + wi * 32 + 16 + fi];
+                    nb0 = Bs[row + wj * 32 + fi];
+                    nb1 = Bs[row + wj * 32 + 16 + fi];
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = na0;
+                a1 = na1;
+                b0 = nb0;
+                b1 = nb1;
+            }
+        }
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(creg[0][0][0]), "+v"(creg[0][0][1]), "+v"(creg[0][0][2]), "+v"(creg[0][0][3]),
+                           "+v"(creg[0][1][0]), "+v"(creg[0][1][1]), "+v"(creg[0][1][2]), "+v"(creg[0][1][3]),
+                           "+v"(creg[1][0][0]), "+v"(creg[1][0][1]), "+v"(creg[1][0][2]), "+v"(creg[1][0][3])
+                         :
+                         : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(creg[1][1][0]), "+v"(creg[1][1][1]), "+v"(creg[1][1][2]), "+v"(creg[1][1][3]),
+                           "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]),
+                           "+v"(va[7])
+                         :
+                         : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]),
+                           "+v"(vb[7])
+                         :
+                         : "memory");
+        // park the PB operands in the other half (its last readers finished before the previous closing barrier)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            *reinterpret_cast<double2v*>(&L1[m * kLdsRow + c]) = va[it];
+            *reinterpret_cast<double2v*>(&L1[(64 + m) * kLdsRow + c]) = vb[it];
+        }
+        __syncthreads();
+        // ---- half 1: PB operands; requests: the NEXT tile's PA operands (the last tile re-requests itself, unused)
+        const bool more = tn < t1;   // workgroup-uniform
+        int nbi = bi, nbj = bj;
+        if (more)
+            pair_tile_index(n_blk, c0, tn, nbi, nbj);
+        double2v wa[8], wb[8];
+        const double* qa[8];
+        const double* qb[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            qa[it] = PA + (int64_t)m * ld + nbi * kNB + c;
+            qb[it] = PA + (int64_t)m * ld + nbj * kNB + c;
+        }
+        {
+            const double* As = L1;
+            const double* Bs = L1 + 64 * kLdsRow;
+            double a0 = -As[fk * kLdsRow + wi * 32 + fi], a1 = -As[fk * kLdsRow + wi * 32 + 16 + fi];
+            double b0 = Bs[fk * kLdsRow + wj * 32 + fi], b1 = Bs[fk * kLdsRow + wj * 32 + 16 + fi];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks < 8) {
+                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wa[ks]) : "v"(qa[ks]) : "memory");
+                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(wb[ks]) : "v"(qb[ks]) : "memory");
+                }
+                double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
+                if (ks < 15) {
+                    const int row = ((ks + 1) * 4 + fk) * kLdsRow;
+                    na0 = -As[row + wi * 32 + fi];
+                    na1 = -As[row + wi * 32 + 16 + fi];
+                    nb0 = Bs[row + wj * 32 + fi];
+                    nb1 = Bs[row + wj * 32 + 16 + fi];
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = na0;
+                a1 = na1;
+                b0 = nb0;
+                b1 = nb1;
+            }
+        }
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(wa[4]), "+v"(wa[5]), "+v"(wa[6]),
+                           "+v"(wa[7])
+                         :
+                         : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(wb[0]), "+v"(wb[1]), "+v"(wb[2]), "+v"(wb[3]), "+v"(wb[4]), "+v"(wb[5]), "+v"(wb[6]),
+                           "+v"(wb[7])
+                         :
+                         : "memory");
+        // (stores behind the wait: on gfx9 they count in vmcnt too)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __builtin_nontemporal_store(creg[a][b][r] + acc[a][b][r],
+                                                &S[(int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi]);
+        // park the next tile's PA operands (half 0 was last read before the barrier in the middle of this iteration)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = idx >> 5, c = (idx & 31) * 2;
+            *reinterpret_cast<double2v*>(&L0[m * kLdsRow + c]) = wa[it];
+            *reinterpret_cast<double2v*>(&L0[(64 + m) * kLdsRow + c]) = wb[it];
+        }
+        __syncthreads();
+        bi = nbi;
+        bj = nbj;
+        t = tn;
+        tn = slot[2 + (iter & 1)];
+        if (t >= t1)
             break;
     }
 }
@@ -1621,15 +1861,19 @@ __global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
         df2::role<false>(a, j, j, smem);
 }
 
-// One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their
-// own column from panel k-1), the others apply the trailing update of panel k-1 to the columns >= k+1.
-// The two parts touch disjoint tiles and both only need results of the previous launch, so the update
+// One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their own column
+// from the pending panels k-1 and, for even k, k-2), the others apply a rank-128 trailing update: launches 2m and 2m+1
+// share the update of the panels 2m-2 and 2m-1 (PA, PB) on the block columns >= c0 = 2m+1 (tiles [t0, t1) of
+// pair_tile_index each; launch 2m takes block column 2m+1, which the next panel needs, and about half of the rest).
+// The two parts of a launch touch disjoint tiles and both only need results of earlier launches, so the update
 // (throughput work) runs beside the latency-bound panel instead of in front of it.
 __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int n_blk,
                                                    int k, int n_panel, double* __restrict__ Pcur,
-                                                   const double* __restrict__ Pprev, double* __restrict__ dinv,
-                                                   double* __restrict__ Ld, double* __restrict__ Linv, int n_upd,
-                                                   int n_upd_wg, unsigned* tile_ctr)
+                                                   const double* __restrict__ Pprev, const double* __restrict__ Pprev2,
+                                                   double* __restrict__ dinv, double* __restrict__ Ld,
+                                                   double* __restrict__ Linv, const double* __restrict__ PA,
+                                                   const double* __restrict__ PB, int c0, int t0, int t1, int n_upd_wg,
+                                                   unsigned* tile_ctr)
 {
     if (ctl->done)
         return;
@@ -1637,19 +1881,19 @@ __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restric
         phase_stamp(ctl, 3);
     if (ctl->lin_fail)
         return;
-    // the tile counter of launch k is word k & 1; launch k resets the other word for launch k + 1 (launch 0 has no
-    // trailing update and resets word 1: whatever an earlier factorisation left behind, word k & 1 is zero at launch k)
+    // the tile counter of launch k is word k & 1; launch k resets the other word for launch k + 1 (launches 0 and 1
+    // have no trailing update: whatever an earlier factorisation left behind, word k & 1 is zero at launch k)
     if (blockIdx.x == 0 && threadIdx.x == 0)
         tile_ctr[(k + 1) & 1] = 0u;
     __shared__ __attribute__((aligned(16))) double smem[kStepSmem];
     if ((int)blockIdx.x < n_panel) {
-        chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, dinv, Ld, smem);
-        if (n_upd > 0) {   // the panel is stored: help with the trailing update of panel k-1
+        chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, Pprev2, dinv, Ld, smem);
+        if (t1 > t0) {   // the panel is stored: help with the trailing update
             __syncthreads();
-            chol_update_wg(S, ld, n_blk, k - 1, tile_ctr + (k & 1), n_upd, Pprev, smem);
+            chol_update2_wg(S, ld, n_blk, c0, tile_ctr + (k & 1), t0, t1, PA, PB, smem);
         }
     } else if ((int)blockIdx.x < n_panel + n_upd_wg)
-        chol_update_wg(S, ld, n_blk, k - 1, tile_ctr + (k & 1), n_upd, Pprev, smem);
+        chol_update2_wg(S, ld, n_blk, c0, tile_ctr + (k & 1), t0, t1, PA, PB, smem);
     else   // last workgroup of launches k >= 1: invert the diagonal factor of block k-1
         chol_inverse_wg(Ld + (int64_t)(k - 1) * 4096, dinv + (k - 1) * kNB, Linv + (int64_t)(k - 1) * 4096, smem);
 }
@@ -1729,14 +1973,27 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
     for (int k = 0; k < n_blk; ++k) {
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
         const int n_panel = 1 + (rows_below + 63) / 64;
-        const int n_upd = k > 0 ? update_tiles(n_blk, k - 1) : 0;
-        // all workgroups of a launch resident at once (one per CU: 134 KB of LDS): the update workgroups
+        // the pair of panels 2m-2, 2m-1 on the block columns >= c0 = 2m+1, shared by the launches 2m and 2m+1
+        const int m = k / 2, c0 = 2 * m + 1;
+        int t0 = 0, t1 = 0;
+        if (k >= 2 && c0 <= n_blk - 1) {
+            const int n_first = n_blk - c0 + 1;
+            const int total = n_first + update_tiles(n_blk, c0 - 1);
+            const int half = std::max(n_first, (total + 1) / 2);
+            t0 = (k & 1) ? half : 0;
+            t1 = (k & 1) ? total : half;
+        }
+        const int n_upd = t1 - t0;
+        // all workgroups of a launch resident at once (one per CU: 160 KB of LDS): the update workgroups
         // share the CUs the panel leaves free and loop over the tiles
         const int n_upd_wg = std::min(n_upd, std::max(e.n_cu - n_panel - 1, e.n_cu / 4));
+        const double* const Pprev = k > 0 ? (const double*)e.P4[(k - 1) & 3] : (const double*)nullptr;
+        const double* const Pprev2 = (k >= 2 && !(k & 1)) ? (const double*)e.P4[(k - 2) & 3] : (const double*)nullptr;
+        const double* const PA = k >= 2 ? (const double*)e.P4[(2 * m - 2) & 3] : (const double*)nullptr;
+        const double* const PB = k >= 2 ? (const double*)e.P4[(2 * m - 1) & 3] : (const double*)nullptr;
         hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd_wg + (k > 0 ? 1 : 0)), dim3(256), 0, e.stream, ctl, S, ld,
-                           n_pad, n_blk, k, n_panel, e.P2[k & 1],
-                           k > 0 ? (const double*)e.P2[(k - 1) & 1] : (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
-                           n_upd, n_upd_wg, e.flags + 258);
+                           n_pad, n_blk, k, n_panel, e.P4[k & 3], Pprev, Pprev2, e.dinv, e.Ldiag, e.Linv, PA, PB, c0, t0,
+                           t1, n_upd_wg, e.flags + 258);
         if (getenv("VMM_BA_DEBUG")) {
             const hipError_t le = hipPeekAtLastError();
             if (le != hipSuccess)

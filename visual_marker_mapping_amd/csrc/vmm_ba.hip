@@ -361,8 +361,8 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
 static int setup_lookahead(Engine& e, int n_blk_max, int ld)
 {
     (void)n_blk_max;
-    e.P2[0] = e.P;
-    e.P2[1] = e.P + (size_t)kNB * ld;
+    for (int i = 0; i < 4; ++i)
+        e.P4[i] = e.P + (size_t)i * kNB * ld;
     return VMM_BA_OK;
 }
 
@@ -1324,7 +1324,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     }
     if ((rc = dev_alloc(e, &e.S, (size_t)e.ldz * e.ldz))) return fail(rc);
     if (e.multi && (rc = dev_alloc(e, &e.S_packed, (size_t)(e.n_pad + 1) * (e.n_pad + 2) / 2))) return fail(rc);
-    if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * e.ldz))) return fail(rc);
+    if ((rc = dev_alloc(e, &e.P, (size_t)4 * kNB * e.ldz))) return fail(rc);
     if ((rc = setup_lookahead(e, e.n_blk, e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.dinv, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
@@ -1926,7 +1926,7 @@ static int make_scratch(Engine& e, int device, int ld)
             e.n_cu = prop.multiProcessorCount;
     }
     int rc;
-    if ((rc = dev_alloc(e, &e.P, (size_t)2 * kNB * ld))) return rc;
+    if ((rc = dev_alloc(e, &e.P, (size_t)4 * kNB * ld))) return rc;
     if ((rc = setup_lookahead(e, ld / kNB, ld))) return rc;
     if ((rc = dev_alloc(e, &e.dinv, (size_t)ld + kNB))) return rc;
     if ((rc = dev_alloc(e, &e.Ldiag, (size_t)(ld / kNB + 1) * 4096))) return rc;
