@@ -105,8 +105,8 @@ def test_cholesky_reports_indefinite_matrix(eng):
 
 @pytest.mark.parametrize("env", [{"VMM_BA_NO_DATAFLOW": "1"}, {"VMM_BA_NO_CHAIN": "1"}])
 def test_cholesky_fallback_paths(eng, monkeypatch, env):
-    """One k_chol_step launch per block column (reduced systems of more than 48 blocks take this path) and the
-    per-block back-substitution kernels, forced at sizes the dataflow kernel would otherwise handle (all of its
+    """One k_chol_step launch per block column for ALL columns (the path of a pass that is redone after a spin gave
+    up; larger systems use it for their leading columns) and the per-block back-substitution kernels, forced at sizes the dataflow kernel would otherwise handle (all of its
     workgroups resident at 1200, five times as many as compute units at 3000)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -126,9 +126,10 @@ def test_cholesky_fallback_paths(eng, monkeypatch, env):
 @pytest.mark.parametrize("n", [1408, 2048, 3072, 3136, 6000])
 def test_cholesky_large_orders(eng, n):
     """22 to 48 blocks (1408, 2048, 3072): k_chol_dataflow with more workgroups than compute units (275 to 1224; only a
-    prefix is resident, see dataflow_max_workgroups).  49 blocks and more (3136, 6000): the looping trailing-update
-    workgroups of k_chol_step (tiles from an atomic counter, asm-requested operands, LDS ping-pong) -- the path behind
-    the 2000 x 1000 figures."""
+    prefix is resident, see dataflow_max_workgroups).  49 blocks and more (3136, 6000): one k_chol_step launch per block
+    column for the leading 16 / 60 columns (rank-128 trailing updates shared by pairs of launches, tiles from an atomic
+    counter, asm-requested operands, LDS ping-pong), one update-only launch, then k_chol_dataflow on the trailing 33 / 34
+    block columns -- the path behind the 2000 x 1000 figures."""
     rng = np.random.default_rng(n)
     B = rng.standard_normal((n, n // 4))
     A = B @ B.T + np.diag(rng.uniform(1.0, 2.0, n)) * n

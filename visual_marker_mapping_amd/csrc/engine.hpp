@@ -276,6 +276,7 @@ void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl, bool safe = false);
 void launch_chol_inverse(Engine& e, int k);
 int dataflow_max_workgroups(int n_cu);
+int dataflow_blocks(int n_blk, int n_cu);   // trailing block columns factored by k_chol_dataflow (n_blk: all; 0: none)
 int dataflow_workgroups(int n_blk);   // workgroups of k_chol_dataflow (must all fit on the chip at one per CU)
 // kernels_cov.hip
 void launch_cov_prepare(Engine& e);

@@ -1945,32 +1945,58 @@ int dataflow_max_workgroups(int n_cu)
     return n_cu > kMaxBlocks ? std::max(n_cu, dataflow_workgroups(kMaxBlocks)) : n_cu;
 }
 
+// How many of the LAST block columns of an n_blk-column system the one-launch kernel factors: all of them when it may
+// (dataflow_max_workgroups), else a tail -- the launches of k_chol_step near the end are bound by their panel chain
+// (~25-31 us per block column at n = 6000, whatever the trailing update costs) while the dataflow kernel needs ~14 us
+// per column at 24 to 38 columns.  VMM_BA_CHOL_TAIL sets the tail length (0: none).
+int dataflow_blocks(int n_blk, int n_cu)
+{
+    if (dataflow_workgroups(n_blk) <= dataflow_max_workgroups(n_cu))
+        return n_blk;
+    static const int env = [] {
+        const char* v = getenv("VMM_BA_CHOL_TAIL");
+        return v ? atoi(v) : -1;
+    }();
+    int tail = env >= 0 ? env : 34;
+    if (dataflow_workgroups(tail) > dataflow_max_workgroups(n_cu) || n_blk > n_cu)
+        return 0;
+    tail = std::min(tail, n_blk - 2);
+    return tail - ((n_blk - tail) & 1);   // the step launches come in pairs: an even number of them in front
+}
+
+static void launch_dataflow(Engine& e, double* S, int n_pad, int ld, LmCtl* ctl, int first_blk, int n_blk)
+{
+    DfArgs a;
+    a.ctl = ctl;
+    a.S = S + (int64_t)first_blk * kNB * (ld + 1);
+    a.ld = ld;
+    a.n_pad = n_pad - first_blk * kNB;
+    a.n_blk = n_blk - first_blk;
+    a.dinv = e.dinv + first_blk * kNB;
+    a.Ld = e.Ldiag + (int64_t)first_blk * 4096;
+    a.Linv = e.Linv + (int64_t)first_blk * 4096;
+    a.G = e.df_gran;
+    a.epoch_word = e.flags + 256;
+    a.abort_word = e.flags + 257;
+    a.spin_limit = 0;
+    hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
+}
+
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl, bool safe)
 {
     const int n_blk = n_pad / kNB;
     const bool chain = n_blk <= e.n_cu && e.flags && e.gran && !e.no_chain && !safe;
-    if (chain && e.df_gran && !e.no_dataflow && dataflow_workgroups(n_blk) <= dataflow_max_workgroups(e.n_cu)) {
+    const int n_df = (chain && e.df_gran && !e.no_dataflow) ? dataflow_blocks(n_blk, e.n_cu) : 0;
+    if (n_df == n_blk) {
         // one launch for the factorisation + forward substitution, one for the back-substitution chain (which
         // bumps the epoch both kernels tag their granules with)
-        DfArgs a;
-        a.ctl = ctl;
-        a.S = S;
-        a.ld = ld;
-        a.n_pad = n_pad;
-        a.n_blk = n_blk;
-        a.dinv = e.dinv;
-        a.Ld = e.Ldiag;
-        a.Linv = e.Linv;
-        a.G = e.df_gran;
-        a.epoch_word = e.flags + 256;
-        a.abort_word = e.flags + 257;
-        a.spin_limit = 0;
-        hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(n_blk)), dim3(256), 0, e.stream, a);
+        launch_dataflow(e, S, n_pad, ld, ctl, 0, n_blk);
         hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
                            e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
         return;
     }
-    for (int k = 0; k < n_blk; ++k) {
+    const int n_step = n_blk - n_df;   // block columns factored by one k_chol_step launch each (even when a tail follows)
+    for (int k = 0; k < n_step; ++k) {
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
         const int n_panel = 1 + (rows_below + 63) / 64;
         // the pair of panels 2m-2, 2m-1 on the block columns >= c0 = 2m+1, shared by the launches 2m and 2m+1
@@ -2000,6 +2026,19 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
                 fprintf(stderr, "[vmm_ba debug] k_chol_step k=%d grid=%d: %s\n", k, n_panel + n_upd_wg + (k > 0 ? 1 : 0),
                         hipGetErrorString(le));
         }
+    }
+    if (n_df > 0) {
+        // hand-over to the one-launch kernel: the pair of panels n_step-2, n_step-1 is still pending on every block
+        // column >= n_step -- one update-only launch (with the inverse of diagonal block n_step-1), then the dataflow
+        // factorisation of the trailing n_df x n_df blocks (+ right-hand side row)
+        const int c0 = n_step;
+        const int total = (n_blk - c0 + 1) + update_tiles(n_blk, c0 - 1);
+        const int n_upd_wg = std::min(total, e.n_cu - 1);
+        hipLaunchKernelGGL(k_chol_step, dim3(n_upd_wg + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, n_step, 0,
+                           (double*)nullptr, (const double*)nullptr, (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
+                           (const double*)e.P4[(n_step - 2) & 3], (const double*)e.P4[(n_step - 1) & 3], c0, 0, total,
+                           n_upd_wg, e.flags + 258);
+        launch_dataflow(e, S, n_pad, ld, ctl, n_step, n_blk);
     }
     // one chained launch while every workgroup of the chain is certainly resident (one per CU); the per-block
     // kernels otherwise

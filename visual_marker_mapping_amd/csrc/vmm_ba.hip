@@ -1331,9 +1331,11 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.Linv, (size_t)(e.n_blk + 1) * 4096))) return fail(rc);
     if ((rc = dev_alloc(e, &e.flags, 264))) return fail(rc);
     if ((rc = dev_alloc(e, &e.gran, (size_t)2 * e.ldz))) return fail(rc);
-    if (!e.no_dataflow && dataflow_workgroups(e.n_blk) <= dataflow_max_workgroups(e.n_cu)
-        && (rc = dev_alloc(e, &e.df_gran, (size_t)e.n_blk * (e.n_blk + 1) / 2 * 8 * 1024)))
-        return fail(rc);
+    {
+        const size_t nd = e.no_dataflow ? 0 : (size_t)dataflow_blocks(e.n_blk, e.n_cu);
+        if (nd > 0 && (rc = dev_alloc(e, &e.df_gran, nd * (nd + 1) / 2 * 8 * 1024)))
+            return fail(rc);
+    }
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.step_comm, (size_t)7 * e.n_e + 1))) return fail(rc);
     if ((rc = dev_alloc(e, &e.cost_comm, 2))) return fail(rc);
@@ -1938,8 +1940,8 @@ static int make_scratch(Engine& e, int device, int ld)
     read_spin_debug_env(e);
     {
         const int nb = ld / kNB - 1;   // ld = n_pad + 64
-        if (!e.no_dataflow && dataflow_workgroups(nb) <= dataflow_max_workgroups(e.n_cu)
-            && (rc = dev_alloc(e, &e.df_gran, (size_t)nb * (nb + 1) / 2 * 8 * 1024)))
+        const size_t nd = e.no_dataflow ? 0 : (size_t)dataflow_blocks(nb, e.n_cu);
+        if (nd > 0 && (rc = dev_alloc(e, &e.df_gran, nd * (nd + 1) / 2 * 8 * 1024)))
             return rc;
     }
     if ((rc = dev_alloc(e, &e.ctl, 1))) return rc;
