@@ -1862,9 +1862,12 @@ __global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
 }
 
 // One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their own column
-// from the pending panels k-1 and, for even k, k-2), the others apply a rank-128 trailing update: launches 2m and 2m+1
-// share the update of the panels 2m-2 and 2m-1 (PA, PB) on the block columns >= c0 = 2m+1 (tiles [t0, t1) of
+// from the pending panels k-1 and, for even k of the paired launches, k-2), the others apply a trailing update.  While
+// the update is what a launch waits for (more than kPairMinBlocks block columns left) it is a rank-128 one: launches 2m
+// and 2m+1 share the update of the panels 2m-2 and 2m-1 (PA, PB) on the block columns >= c0 = 2m+1 (tiles [t0, t1) of
 // pair_tile_index each; launch 2m takes block column 2m+1, which the next panel needs, and about half of the rest).
+// Near the end a launch is as long as its panel chain and the second lazy panel of the paired form (+6 us on every other
+// launch) costs more than the saved traffic: PB == nullptr = the rank-64 update of panel k-1 (PA) on the columns >= k+1.
 // The two parts of a launch touch disjoint tiles and both only need results of earlier launches, so the update
 // (throughput work) runs beside the latency-bound panel instead of in front of it.
 __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int n_blk,
@@ -1890,11 +1893,17 @@ __global__ __launch_bounds__(256) void k_chol_step(LmCtl* ctl, double* __restric
         chol_panel_wg(ctl, S, ld, n_pad, k, Pcur, Pprev, Pprev2, dinv, Ld, smem);
         if (t1 > t0) {   // the panel is stored: help with the trailing update
             __syncthreads();
-            chol_update2_wg(S, ld, n_blk, c0, tile_ctr + (k & 1), t0, t1, PA, PB, smem);
+            if (PB)
+                chol_update2_wg(S, ld, n_blk, c0, tile_ctr + (k & 1), t0, t1, PA, PB, smem);
+            else
+                chol_update_wg(S, ld, n_blk, c0 - 2, tile_ctr + (k & 1), t1, PA, smem);
         }
-    } else if ((int)blockIdx.x < n_panel + n_upd_wg)
-        chol_update2_wg(S, ld, n_blk, c0, tile_ctr + (k & 1), t0, t1, PA, PB, smem);
-    else   // last workgroup of launches k >= 1: invert the diagonal factor of block k-1
+    } else if ((int)blockIdx.x < n_panel + n_upd_wg) {
+        if (PB)
+            chol_update2_wg(S, ld, n_blk, c0, tile_ctr + (k & 1), t0, t1, PA, PB, smem);
+        else   // rank-64 update of the single panel PA on the block columns >= c0 (tiles [0, t1))
+            chol_update_wg(S, ld, n_blk, c0 - 2, tile_ctr + (k & 1), t1, PA, smem);
+    } else   // last workgroup of launches k >= 1: invert the diagonal factor of block k-1
         chol_inverse_wg(Ld + (int64_t)(k - 1) * 4096, dinv + (k - 1) * kNB, Linv + (int64_t)(k - 1) * 4096, smem);
 }
 
@@ -1914,6 +1923,8 @@ void launch_chol_inverse(Engine& e, int k)
     hipLaunchKernelGGL(k_chol_inverse, dim3(1), dim3(256), 0, e.stream, (const LmCtl*)e.ctl, (const double*)e.Ldiag,
                        (const double*)e.dinv, e.Linv, k);
 }
+
+constexpr int kPairMinBlocks = 46;   // block columns left below which the launches stop pairing their trailing updates
 
 static int update_tiles(int n_blk, int k)   // tiles of the trailing update of panel k: columns >= k+2
 {
@@ -1996,27 +2007,43 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         return;
     }
     const int n_step = n_blk - n_df;   // block columns factored by one k_chol_step launch each (even when a tail follows)
+    // launches k < k_pair are paired (rank-128 updates), launch k_pair finishes the last pair alone, later ones are
+    // single (rank-64): measured at n = 6000, the pair wins while more than ~46 block columns are left
+    int k_pair = 0;
+    while (n_blk - k_pair > kPairMinBlocks)
+        k_pair += 2;
+    if (k_pair > n_step)
+        k_pair = n_step;       // (n_step is even when a tail follows, and then the hand-over finishes the last pair)
     for (int k = 0; k < n_step; ++k) {
         const int rows_below = n_pad + 1 - (k + 1) * kNB;
         const int n_panel = 1 + (rows_below + 63) / 64;
-        // the pair of panels 2m-2, 2m-1 on the block columns >= c0 = 2m+1, shared by the launches 2m and 2m+1
-        const int m = k / 2, c0 = 2 * m + 1;
-        int t0 = 0, t1 = 0;
-        if (k >= 2 && c0 <= n_blk - 1) {
-            const int n_first = n_blk - c0 + 1;
-            const int total = n_first + update_tiles(n_blk, c0 - 1);
-            const int half = std::max(n_first, (total + 1) / 2);
-            t0 = (k & 1) ? half : 0;
-            t1 = (k & 1) ? total : half;
+        int c0 = k + 1, t0 = 0, t1 = 0;
+        const double *PA = nullptr, *PB = nullptr, *Pprev2 = nullptr;
+        const double* const Pprev = k > 0 ? (const double*)e.P4[(k - 1) & 3] : (const double*)nullptr;
+        if (k >= 2 && k <= k_pair) {
+            // the pair of panels 2m-2, 2m-1 on the block columns >= c0 = 2m+1, shared by the launches 2m and 2m+1
+            // (launch k_pair: all of it)
+            const int m = k / 2;
+            c0 = 2 * m + 1;
+            PA = e.P4[(2 * m - 2) & 3];
+            PB = e.P4[(2 * m - 1) & 3];
+            if (!(k & 1))
+                Pprev2 = e.P4[(k - 2) & 3];
+            if (c0 <= n_blk - 1) {
+                const int n_first = n_blk - c0 + 1;
+                const int total = n_first + update_tiles(n_blk, c0 - 1);
+                const int half = k == k_pair ? total : std::max(n_first, (total + 1) / 2);
+                t0 = (k & 1) ? half : 0;
+                t1 = (k & 1) ? total : half;
+            }
+        } else if (k >= 1 && k > k_pair) {
+            PA = Pprev;                                  // panel k-1 on the block columns >= k+1
+            t1 = update_tiles(n_blk, k - 1);
         }
         const int n_upd = t1 - t0;
         // all workgroups of a launch resident at once (one per CU: 160 KB of LDS): the update workgroups
         // share the CUs the panel leaves free and loop over the tiles
         const int n_upd_wg = std::min(n_upd, std::max(e.n_cu - n_panel - 1, e.n_cu / 4));
-        const double* const Pprev = k > 0 ? (const double*)e.P4[(k - 1) & 3] : (const double*)nullptr;
-        const double* const Pprev2 = (k >= 2 && !(k & 1)) ? (const double*)e.P4[(k - 2) & 3] : (const double*)nullptr;
-        const double* const PA = k >= 2 ? (const double*)e.P4[(2 * m - 2) & 3] : (const double*)nullptr;
-        const double* const PB = k >= 2 ? (const double*)e.P4[(2 * m - 1) & 3] : (const double*)nullptr;
         hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd_wg + (k > 0 ? 1 : 0)), dim3(256), 0, e.stream, ctl, S, ld,
                            n_pad, n_blk, k, n_panel, e.P4[k & 3], Pprev, Pprev2, e.dinv, e.Ldiag, e.Linv, PA, PB, c0, t0,
                            t1, n_upd_wg, e.flags + 258);
@@ -2028,16 +2055,19 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         }
     }
     if (n_df > 0) {
-        // hand-over to the one-launch kernel: the pair of panels n_step-2, n_step-1 is still pending on every block
-        // column >= n_step -- one update-only launch (with the inverse of diagonal block n_step-1), then the dataflow
-        // factorisation of the trailing n_df x n_df blocks (+ right-hand side row)
+        // hand-over to the one-launch kernel: what is still pending on every block column >= n_step (the pair of panels
+        // n_step-2, n_step-1 when the last launch was a paired one, else panel n_step-1) -- one update-only launch
+        // (with the inverse of diagonal block n_step-1), then the dataflow factorisation of the trailing n_df x n_df
+        // blocks (+ right-hand side row)
+        const bool pair = n_step <= k_pair;
         const int c0 = n_step;
-        const int total = (n_blk - c0 + 1) + update_tiles(n_blk, c0 - 1);
+        const int total = pair ? (n_blk - c0 + 1) + update_tiles(n_blk, c0 - 1) : update_tiles(n_blk, c0 - 2);
         const int n_upd_wg = std::min(total, e.n_cu - 1);
         hipLaunchKernelGGL(k_chol_step, dim3(n_upd_wg + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, n_step, 0,
                            (double*)nullptr, (const double*)nullptr, (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
-                           (const double*)e.P4[(n_step - 2) & 3], (const double*)e.P4[(n_step - 1) & 3], c0, 0, total,
-                           n_upd_wg, e.flags + 258);
+                           (const double*)e.P4[(n_step - (pair ? 2 : 1)) & 3],
+                           pair ? (const double*)e.P4[(n_step - 1) & 3] : (const double*)nullptr, c0, 0, total, n_upd_wg,
+                           e.flags + 258);
         launch_dataflow(e, S, n_pad, ld, ctl, n_step, n_blk);
     }
     // one chained launch while every workgroup of the chain is certainly resident (one per CU); the per-block
