@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <functional>
 #include <vector>
@@ -1807,6 +1808,8 @@ int vmm_ba_tag_translation_covariance(vmm_ba_handle h, int robustify, double hub
     return VMM_BA_OK;
 }
 
+constexpr int kMaxProjectDevices = 64;
+
 int vmm_ba_project_points(const double intr[4], const double dist[5], int64_t n, const double* points_cam,
                           double* uv, int device)
 {
@@ -1820,20 +1823,34 @@ int vmm_ba_project_points(const double intr[4], const double dist[5], int64_t n,
     Intrinsics K;
     K.fx = intr[0]; K.fy = intr[1]; K.cx = intr[2]; K.cy = intr[3];
     K.k1 = dist[0]; K.k2 = dist[1]; K.p1 = dist[2]; K.p2 = dist[3]; K.k3 = dist[4];
-    double *d_p = nullptr, *d_uv = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_p, sizeof(double) * 3 * n));
-    if (hipMalloc((void**)&d_uv, sizeof(double) * 2 * n) != hipSuccess) {
-        (void)hipFree(d_p);
-        set_error("hipMalloc failed");
-        return VMM_BA_ERR_HIP;
+    // CameraModel::projectPoint is called point by point by its users: the device buffer of small calls is kept per
+    // device (grown on demand, up to 1 M points = 40 MB; larger calls allocate and free), calls are serialised
+    static std::mutex mu;
+    static double* cache[kMaxProjectDevices] = {};
+    static int64_t cache_cap[kMaxProjectDevices] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    const bool cached = n <= (int64_t)1 << 20 && device >= 0 && device < kMaxProjectDevices;
+    double* buf = nullptr;
+    if (cached && cache_cap[device] >= n) {
+        buf = cache[device];
+    } else {
+        const int64_t cap = cached ? std::max<int64_t>(n, 1024) : n;
+        HIP_TRY(hipMalloc((void**)&buf, sizeof(double) * 5 * (size_t)cap));
+        if (cached) {
+            if (cache[device])
+                (void)hipFree(cache[device]);
+            cache[device] = buf;
+            cache_cap[device] = cap;
+        }
     }
+    double *d_p = buf, *d_uv = buf + 3 * n;
     hipError_t err = hipMemcpy(d_p, points_cam, sizeof(double) * 3 * n, hipMemcpyHostToDevice);
     if (err == hipSuccess) {
         launch_project(nullptr, K, n, d_p, d_uv);
         err = hipMemcpy(uv, d_uv, sizeof(double) * 2 * n, hipMemcpyDeviceToHost);
     }
-    (void)hipFree(d_p);
-    (void)hipFree(d_uv);
+    if (!cached)
+        (void)hipFree(buf);
     if (err != hipSuccess) {
         set_error(std::string("project_points: ") + hipGetErrorString(err));
         return VMM_BA_ERR_HIP;
