@@ -188,6 +188,34 @@ def test_tag_translation_covariance_matches_oracle(oracle, elim, robust):
         assert np.all(np.linalg.eigvalsh(cov[t]) > 0)
 
 
+@pytest.mark.parametrize("n_tags", [260, 560])
+def test_tag_translation_covariance_on_every_factorisation_path(monkeypatch, n_tags):
+    """The covariance needs the factor, the reciprocal diagonals and the inverse of EVERY diagonal block.  Reduced tag
+    systems of 25 blocks (k_chol_dataflow with more workgroups than compute units) and 53 blocks (k_chol_step for the
+    leading columns + k_chol_dataflow on the trailing ones) against the same handle data factored by one k_chol_step
+    launch per block column (VMM_BA_NO_DATAFLOW=1, read at create)."""
+    from visual_marker_mapping_amd import engine
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(1, n_cams=2 * n_tags, n_tags=n_tags, visibility=0.1)
+    covs = []
+    for no_df in ("0", "1"):
+        monkeypatch.setenv("VMM_BA_NO_DATAFLOW", no_df)
+        ba = engine.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, 0, s.obs_cam, s.obs_tag, s.obs_px,
+                                   elimination=engine.ELIM_CAMERAS)
+        try:
+            out = ba.solve(engine.default_options(robustify=0))
+            assert out["termination_type"] == engine.CONVERGENCE and out["num_sync_timeouts"] == 0
+            ba.set_state(s.cam_gt, s.tag_gt)              # the same point for both handles
+            covs.append(ba.tag_translation_covariance(robustify=False))
+        finally:
+            ba.close()
+    assert np.all(covs[0][0] == 0.0)
+    for t in range(1, n_tags):
+        scale = np.abs(covs[1][t]).max()
+        assert scale > 0
+        np.testing.assert_allclose(covs[0][t], covs[1][t], rtol=0, atol=1e-9 * scale)
+
+
 @pytest.mark.parametrize("config", [1, 5])
 def test_f32_accumulate_precision_reaches_the_f64_optimum(oracle, config):
     """VMM_BA_PRECISION_F32_ACCUM (BASELINE.json configs[3]): J^T J blocks in f32, residuals / gradient /

@@ -51,39 +51,76 @@ def audit(lines):
     """Returns (number of asm loads, number of asm waits, list of violations) for k_chol_step."""
     start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL) and l.rstrip().split(":")[0].startswith(KERNEL))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end") )
-    pending = {}      # register -> line number of the load that will fill it
-    in_asm = False
-    n_loads = n_waits = 0
+    pending = {}      # register -> (issue sequence number, line number) of the load that will fill it
+    state = {"in_asm": False, "seq": 0}
+    counts = {"loads": 0, "waits": 0}
     bad = []
+    # loop latches: hipcc rotates the tile loop, so the second half of its body (with the final waits) can sit in front
+    # of the first half (with the requests) in the text -- a request is then followed to its wait around the back edge
+    labels = {}
     for i in range(start + 1, end):
         l = lines[i].strip()
+        if l.startswith(".LBB") and ":" in l:
+            labels[l.split(":")[0]] = i
+    latch = {}
+    for i in range(start + 1, end):
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\w+)", lines[i].strip())
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            latch[i] = labels[m.group(1)]
+
+    def step(i, count):
+        l = lines[i].strip()
         if l.startswith(";;#ASMSTART"):
-            in_asm = True
-            continue
+            state["in_asm"] = True
+            return
         if l.startswith(";;#ASMEND"):
-            in_asm = False
-            continue
+            state["in_asm"] = False
+            return
         if not l or l.startswith(";") or l.startswith(".") or l.endswith(":"):
-            continue
+            return
         code = l.split(";")[0]
-        if in_asm and code.startswith("global_load_dword"):
+        if state["in_asm"] and code.startswith("global_load_dword"):
             dst = code.split(",")[0]
+            state["seq"] += 1
             for r in regs_of(dst):
                 if r in pending:
-                    bad.append((i + 1, "asm load overwrites v%d still pending from line %d" % (r, pending[r])))
-                pending[r] = i + 1
+                    bad.append((i + 1, "asm load overwrites v%d still pending from line %d" % (r, pending[r][1])))
+                pending[r] = (state["seq"], i + 1)
             src = ",".join(code.split(",")[1:])
             for r in regs_of(src) & set(pending) - regs_of(dst):
                 bad.append((i + 1, "asm load addresses through pending v%d" % r))
-            n_loads += 1
-            continue
-        if in_asm and code.startswith("s_waitcnt") and "vmcnt(0)" in code:
-            pending.clear()
-            n_waits += 1
-            continue
+            counts["loads"] += count
+            return
+        m_wait = re.match(r"s_waitcnt\s+vmcnt\((\d+)\)", code) if state["in_asm"] else None
+        if m_wait:
+            # loads return in order: vmcnt(N) leaves the N most recently issued ones in flight
+            keep = int(m_wait.group(1))
+            order = sorted(set(q for q, _ in pending.values()))
+            alive = set(order[len(order) - keep:]) if keep else set()
+            for r in [r for r, (q, _) in pending.items() if q not in alive]:
+                del pending[r]
+            counts["waits"] += count
+            return
         touched = regs_of(code) & set(pending)
         for r in sorted(touched):
-            bad.append((i + 1, "`%s` names v%d between its load (line %d) and the wait" % (code, r, pending[r])))
+            bad.append((i + 1, "`%s` names v%d between its load (line %d) and the wait" % (code, r, pending[r][1])))
+
+    for i in range(start + 1, end):
+        step(i, 1)
+        if i in latch and pending and any(latch[i] < ln - 1 <= i for _, ln in pending.values()):
+            # requests of this loop still in flight at its latch: once more through the body, up to the first of them
+            stop = min(ln for _, ln in pending.values()) - 1
+            saved_asm = state["in_asm"]
+            state["in_asm"] = False
+            for j in range(latch[i], stop):
+                step(j, 0)
+                if not pending:
+                    break
+            state["in_asm"] = saved_asm
+            if pending:
+                bad.append((i + 1, "loads still in flight one loop iteration later: %s" % sorted(pending)))
+                pending.clear()
+    n_loads, n_waits = counts["loads"], counts["waits"]
     if pending:
         bad.append((end, "loads never waited for: %s" % sorted(pending)))
     return n_loads, n_waits, bad

@@ -665,14 +665,6 @@ __device__ __forceinline__ void chol_update2_wg(double* __restrict__ S, int ld, 
         if (tid == 0)   // the tile after the next one, read by everybody behind this iteration's closing barrier
             slot[2 + (iter & 1)] = t0 + (int)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double creg[2][2][4];
-        const double* pc[16];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    pc[8 * a + 4 * b + r] = S + (int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi;
         double2v va[8], vb[8];
         const double* pa[8];
         const double* pb[8];
@@ -689,8 +681,20 @@ __device__ __forceinline__ void chol_update2_wg(double* __restrict__ S, int ld, 
 #pragma unroll
             for (int b = 0; b < 2; ++b)
                 acc[a][b] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-        // ---- half 0: PA operands; requests: this tile's C values, then its PB operands
+        // ---- half 0: PA operands; requests: this tile's PB operands, then its C values.  The C values (HBM, the longer
+        // latency) are only needed behind half 1: the wait at the end of this half leaves the 16 most recent requests --
+        // exactly them -- in flight (loads return in order), so they have both halves to arrive
         {
+            // (the addresses of the C values only live in this half: they are recomputed for the stores -- kept across
+            // half 1 their 32 registers push the compiler into copying `creg` while its loads are still in flight)
+            const double* pc[16];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        pc[8 * a + 4 * b + r] = S + (int64_t)(I0 + wi * 32 + a * 16 + fk + 4 * r) * ld + J0 + wj * 32 + b * 16 + fi;
             const double* As = L0;
             const double* Bs = L0 + 64 * kLdsRow;
             double a0 = -As[fk * kLdsRow + wi * 32 + fi], a1 = -As[fk * kLdsRow + wi * 32 + 16 + fi];
@@ -698,13 +702,14 @@ __device__ __forceinline__ void chol_update2_wg(double* __restrict__ S, int ld, 
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 if (ks < 8) {
-                    __asm__ volatile("global_load_dwordx2 %0, %1, off nt"
-                                     : "=&v"(creg[(2 * ks) >> 3][((2 * ks) >> 2) & 1][(2 * ks) & 3]) : "v"(pc[2 * ks]) : "memory");
-                    __asm__ volatile("global_load_dwordx2 %0, %1, off nt"
-                                     : "=&v"(creg[(2 * ks + 1) >> 3][((2 * ks + 1) >> 2) & 1][(2 * ks + 1) & 3]) : "v"(pc[2 * ks + 1]) : "memory");
+                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[ks]) : "v"(pa[ks]) : "memory");
+                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[ks]) : "v"(pb[ks]) : "memory");
                 } else {
-                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(va[ks - 8]) : "v"(pa[ks - 8]) : "memory");
-                    __asm__ volatile("global_load_dwordx4 %0, %1, off" : "=&v"(vb[ks - 8]) : "v"(pb[ks - 8]) : "memory");
+                    const int q = 2 * (ks - 8);
+                    __asm__ volatile("global_load_dwordx2 %0, %1, off nt"
+                                     : "=&v"(creg[q >> 3][(q >> 2) & 1][q & 3]) : "v"(pc[q]) : "memory");
+                    __asm__ volatile("global_load_dwordx2 %0, %1, off nt"
+                                     : "=&v"(creg[(q + 1) >> 3][((q + 1) >> 2) & 1][(q + 1) & 3]) : "v"(pc[q + 1]) : "memory");
                 }
                 double na0 = 0.0, na1 = 0.0, nb0 = 0.0, nb1 = 0.0;
                 if (ks < 15) {
@@ -724,19 +729,12 @@ __device__ __forceinline__ void chol_update2_wg(double* __restrict__ S, int ld, 
                 b1 = nb1;
             }
         }
-        __asm__ volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(creg[0][0][0]), "+v"(creg[0][0][1]), "+v"(creg[0][0][2]), "+v"(creg[0][0][3]),
-                           "+v"(creg[0][1][0]), "+v"(creg[0][1][1]), "+v"(creg[0][1][2]), "+v"(creg[0][1][3]),
-                           "+v"(creg[1][0][0]), "+v"(creg[1][0][1]), "+v"(creg[1][0][2]), "+v"(creg[1][0][3])
-                         :
-                         : "memory");
-        __asm__ volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(creg[1][1][0]), "+v"(creg[1][1][1]), "+v"(creg[1][1][2]), "+v"(creg[1][1][3]),
-                           "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]),
+        __asm__ volatile("s_waitcnt vmcnt(16)"
+                         : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]),
                            "+v"(va[7])
                          :
                          : "memory");
-        __asm__ volatile("s_waitcnt vmcnt(0)"
+        __asm__ volatile("s_waitcnt vmcnt(16)"
                          : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]),
                            "+v"(vb[7])
                          :
@@ -795,7 +793,14 @@ __device__ __forceinline__ void chol_update2_wg(double* __restrict__ S, int ld, 
             }
         }
         __asm__ volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(wa[4]), "+v"(wa[5]), "+v"(wa[6]),
+                         : "+v"(creg[0][0][0]), "+v"(creg[0][0][1]), "+v"(creg[0][0][2]), "+v"(creg[0][0][3]),
+                           "+v"(creg[0][1][0]), "+v"(creg[0][1][1]), "+v"(creg[0][1][2]), "+v"(creg[0][1][3]),
+                           "+v"(creg[1][0][0]), "+v"(creg[1][0][1]), "+v"(creg[1][0][2]), "+v"(creg[1][0][3])
+                         :
+                         : "memory");
+        __asm__ volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(creg[1][1][0]), "+v"(creg[1][1][1]), "+v"(creg[1][1][2]), "+v"(creg[1][1][3]),
+                           "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(wa[4]), "+v"(wa[5]), "+v"(wa[6]),
                            "+v"(wa[7])
                          :
                          : "memory");
