@@ -304,6 +304,15 @@ int vmm_ba_pose_plus(int64_t n, const double* qt, const double* delta, double* o
  * concurrent run.  Dense elimination, one GPU. */
 int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms);
 
+/* Test hook, host logic only (no device needed): the launch schedule of the launch-per-column Cholesky
+ * (csrc/kernels_chol.hip, chol_step_schedule) for a system of n_blk 64-column blocks whose trailing n_df block columns go
+ * to the one-launch kernel (n_df < 0: the library's own choice for a chip of n_cu compute units).  launches[i] =
+ * { k (-1: update-only hand-over launch), lazy0, lazy1, upd0, upd1 (panel numbers, -1: none), c0, t0, t1 }; at most
+ * `cap` rows are written, *n_launches is the full count, *n_df_used the tail length.  vmm_ba_debug_chol_tile returns the
+ * (block row, block column) of tile t of such a launch's update list. */
+int vmm_ba_debug_chol_schedule(int n_blk, int n_df, int n_cu, int32_t* launches, int cap, int* n_launches, int* n_df_used);
+int vmm_ba_debug_chol_tile(int n_blk, const int32_t* launch, int t, int* bi, int* bj);
+
 /* Times each kernel of an LM iteration at the current state (reps launches each). */
 int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vmm_ba_kernel_times* out);
 

@@ -152,3 +152,78 @@ def test_shard_bounds_cover_and_balance():
     for r, idx in enumerate(idx_all):
         for c in set(oc[idx]):
             assert owners.setdefault(c, r) == r
+
+
+def _replay_chol_schedule(n_blk, n_df, n_cu=256):
+    """Replays the launch schedule of the launch-per-column Cholesky (csrc/kernels_chol.hip, chol_step_schedule) on a
+    model of the block matrix: which panels has every tile (block row i >= block column j; i == n_blk is the right-hand
+    side row) received so far?"""
+    import ctypes as C
+    from visual_marker_mapping_amd import _lib
+    L = _lib.lib()
+    cap = 2 * n_blk + 8
+    rows = np.zeros((cap, 8), np.int32)
+    n, nd = C.c_int(), C.c_int()
+    _lib.check(L.vmm_ba_debug_chol_schedule(n_blk, n_df, n_cu, rows.ctypes.data, cap, C.byref(n), C.byref(nd)))
+    assert n.value <= cap
+    n_df = nd.value
+    n_step = n_blk - n_df
+    applied = {(i, j): set() for j in range(n_blk) for i in range(j, n_blk + 1)}
+    factored_at = {}
+    bi, bj = C.c_int(), C.c_int()
+    for li in range(n.value):
+        row = np.ascontiguousarray(rows[li])
+        k, lazy0, lazy1, u0, u1, c0, t0, t1 = (int(v) for v in row)
+        touched = set()
+        if k >= 0:
+            # the panel workgroups: every update of block column k is in place or applied lazily now, from panels that
+            # earlier launches finished
+            assert k == len(factored_at)
+            lazies = {p for p in (lazy0, lazy1) if p >= 0}
+            assert all(factored_at[p] < li for p in lazies)
+            for i in range(k, n_blk + 1):
+                assert applied[(i, k)].isdisjoint(lazies) and applied[(i, k)] | lazies == set(range(k)), (n_blk, n_df, k, i)
+                touched.add((i, k))
+        else:
+            assert li == n.value - 1 and n_df > 0 and len(factored_at) == n_step
+        ups = [p for p in (u0, u1) if p >= 0]
+        assert 0 <= t0 <= t1 and (t1 == t0 or ups)
+        for t in range(t0, t1):
+            _lib.check(L.vmm_ba_debug_chol_tile(n_blk, row.ctypes.data, t, C.byref(bi), C.byref(bj)))
+            tile = (bi.value, bj.value)
+            assert c0 <= tile[1] <= min(tile[0], n_blk - 1) and tile[0] <= n_blk, (n_blk, n_df, li, t, tile)
+            assert tile not in touched, "two workgroups of one launch on one tile"
+            touched.add(tile)
+            assert tile[1] not in factored_at and tile[1] != k
+            for p in ups:
+                assert factored_at[p] < li and p < tile[1] and p not in applied[tile], (n_blk, n_df, li, t, tile, p)
+                applied[tile].add(p)
+        if k >= 0:
+            factored_at[k] = li
+    assert sorted(factored_at) == list(range(n_step))
+    for j in range(n_step, n_blk):      # what the one-launch kernel takes over is completely updated
+        for i in range(j, n_blk + 1):
+            assert applied[(i, j)] == set(range(n_step)), (n_blk, n_df, i, j)
+    return n_df, rows[:n.value]
+
+
+def test_cholesky_launch_schedule_applies_every_panel_to_every_tile_exactly_once():
+    """Host logic only.  Every size from 1 to 72 block columns and a few large ones, as the library would run them on
+    256 compute units (n_df = -1: its own choice of the dataflow tail; systems the one-launch kernel takes whole return
+    their fallback schedule), with every launch on the step path (n_df = 0: the path of a redone pass), and with other
+    tail lengths: paired and single launches, the finishing launch of the last pair, both hand-over forms."""
+    sizes = list(range(1, 73)) + [80, 93, 94, 95, 112, 128]
+    seen_pairs = seen_tail_pair = seen_tail_single = 0
+    for n_blk in sizes:
+        for n_df in (-1, 0):
+            used, rows = _replay_chol_schedule(n_blk, n_df)
+            seen_pairs += int(np.any(rows[:, 4] >= 0))
+            if used > 0:
+                assert (n_blk - used) % 2 == 0 and rows[-1, 0] == -1
+                seen_tail_pair += int(rows[-1, 4] >= 0)
+                seen_tail_single += int(rows[-1, 4] < 0)
+    for n_blk, n_df in ((50, 2), (51, 3), (60, 34), (94, 10), (94, 44), (94, 60), (100, 48), (128, 80)):
+        used, rows = _replay_chol_schedule(n_blk, n_df)
+        assert used == n_df
+        seen_tail_pair += int(rows[-1, 4] >= 0)
+    assert seen_pairs > 10 and seen_tail_pair > 0 and seen_tail_single > 10

@@ -24,7 +24,8 @@ EXPORTS = ["vmm_ba_last_error", "vmm_ba_abi_version", "vmm_ba_default_options",
            "vmm_ba_enable_rccl",
            "vmm_ba_set_observation_mask", "vmm_ba_solve", "vmm_ba_cost",
            "vmm_ba_reprojection_stats", "vmm_ba_tag_translation_covariance", "vmm_ba_project_points", "vmm_ba_eval_blocks",
-           "vmm_ba_dense_spd_solve", "vmm_ba_dense_syrk", "vmm_ba_time_kernels", "vmm_ba_pose_plus", "vmm_ba_debug_overlap"]
+           "vmm_ba_dense_spd_solve", "vmm_ba_dense_syrk", "vmm_ba_time_kernels", "vmm_ba_pose_plus", "vmm_ba_debug_overlap",
+           "vmm_ba_debug_chol_schedule", "vmm_ba_debug_chol_tile"]
 
 
 class Problem(C.Structure):
@@ -131,6 +132,8 @@ def lib():
         L.vmm_ba_time_kernels.argtypes = [C.c_void_p, C.POINTER(Options), C.c_int,
                                           C.POINTER(KernelTimes)]
         L.vmm_ba_debug_overlap.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vmm_ba_debug_chol_schedule.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.vmm_ba_debug_chol_tile.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 

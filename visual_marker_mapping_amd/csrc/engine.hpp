@@ -276,7 +276,15 @@ void launch_reduce_plan(hipStream_t st, const LmCtl* ctl, const SyrkPlan& p, int
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl, bool safe = false);
 void launch_chol_inverse(Engine& e, int k);
 int dataflow_max_workgroups(int n_cu);
-int dataflow_blocks(int n_blk, int n_cu);   // trailing block columns factored by k_chol_dataflow (n_blk: all; 0: none)
+int dataflow_blocks(int n_blk, int n_cu);
+struct CholLaunch {   // one k_chol_step launch of the launch-per-column factorisation
+    int k;            // block column its panel workgroups factor; -1: the update-only hand-over launch
+    int lazy[2];      // panels those workgroups first apply to their own column (older first; -1: none)
+    int upd[2];       // panels of the launch's trailing update (-1: none; both: rank-128)
+    int c0, t0, t1;   // first block column of the update's tile list, and the range of that list this launch takes
+};
+std::vector<CholLaunch> chol_step_schedule(int n_blk, int n_df);
+void chol_schedule_tile(int n_blk, const CholLaunch& L, int t, int* bi, int* bj);   // trailing block columns factored by k_chol_dataflow (n_blk: all; 0: none)
 int dataflow_workgroups(int n_blk);   // workgroups of k_chol_dataflow (must all fit on the chip at one per CU)
 // kernels_cov.hip
 void launch_cov_prepare(Engine& e);

@@ -393,7 +393,7 @@ extern "C" int vmm_ba_debug_read_stamps(unsigned long long* out, int n)
 // so the kernel pays one memory latency, then 16 k-steps of four v_mfma_f64_16x16x4_f64 per wave.
 typedef double double2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void update_tile_index(int n_blk, int k, int t, int& bi, int& bj)
+__host__ __device__ __forceinline__ void update_tile_index(int n_blk, int k, int t, int& bi, int& bj)
 {
     // tile index -> (bi, bj): columns k+2..min(bi, n_blk-1) (block column k+1 is updated lazily by the
     // panel of that column), rows k+2..n_blk.  Row q = bi - (k+2) holds q + 1 tiles, except the last row (the
@@ -610,7 +610,7 @@ __device__ __forceinline__ void chol_update_wg(double* __restrict__ S, int ld, i
 // while the tile's C values (non-temporal) and its PB operands are requested, half 1 multiplies the PB operands
 // (LDS half `1`) while the NEXT tile's PA operands are requested; C is added and stored behind half 1.  As in
 // chol_update_wg the requests are volatile asm, touched only behind the matching s_waitcnt (tools/check_chol_asm.py).
-__device__ __forceinline__ void pair_tile_index(int n_blk, int c0, int t, int& bi, int& bj)
+__host__ __device__ __forceinline__ void pair_tile_index(int n_blk, int c0, int t, int& bi, int& bj)
 {
     const int n_first = n_blk - c0 + 1;   // block column c0: rows c0 .. n_blk
     if (t < n_first) {
@@ -1980,6 +1980,66 @@ int dataflow_blocks(int n_blk, int n_cu)
     return tail - ((n_blk - tail) & 1);   // the step launches come in pairs: an even number of them in front
 }
 
+// The k_chol_step launches that factor the leading n_blk - n_df block columns (and, when a dataflow tail follows, hand
+// the rest of the matrix over with every update applied).  Pure host logic, also exported for the schedule test
+// (vmm_ba_debug_chol_schedule): tests/test_host_cpu.py replays it for every size and checks that each tile receives
+// each panel exactly once, from a panel of an earlier launch, before its block column is factored.
+//   launches k < k_pair are paired (rank-128 updates: launches 2m and 2m+1 share the pair of panels 2m-2, 2m-1 on the
+//   block columns >= 2m+1), launch k_pair finishes the last pair alone, later ones are single (rank-64: panel k-1 on the
+//   columns >= k+1): measured at n = 6000, the pair wins while more than ~46 block columns are left.
+std::vector<CholLaunch> chol_step_schedule(int n_blk, int n_df)
+{
+    std::vector<CholLaunch> out;
+    const int n_step = n_blk - n_df;   // even when a tail follows (dataflow_blocks)
+    int k_pair = 0;
+    while (n_blk - k_pair > kPairMinBlocks)
+        k_pair += 2;
+    if (k_pair > n_step)
+        k_pair = n_step;       // the hand-over launch then finishes the last pair
+    for (int k = 0; k < n_step; ++k) {
+        CholLaunch L = { k, { -1, k > 0 ? k - 1 : -1 }, { -1, -1 }, k + 1, 0, 0 };
+        if (k >= 2 && k <= k_pair) {
+            const int m = k / 2;
+            L.c0 = 2 * m + 1;
+            L.upd[0] = 2 * m - 2;
+            L.upd[1] = 2 * m - 1;
+            if (!(k & 1))
+                L.lazy[0] = k - 2;
+            if (L.c0 <= n_blk - 1) {
+                const int n_first = n_blk - L.c0 + 1;
+                const int total = n_first + update_tiles(n_blk, L.c0 - 1);
+                // launch 2m takes block column 2m+1 (the next panel needs it) and about half of the rest
+                const int half = k == k_pair ? total : std::max(n_first, (total + 1) / 2);
+                L.t0 = (k & 1) ? half : 0;
+                L.t1 = (k & 1) ? total : half;
+            }
+        } else if (k >= 1 && k > k_pair) {
+            L.upd[0] = k - 1;
+            L.t1 = update_tiles(n_blk, k - 1);
+        }
+        out.push_back(L);
+    }
+    if (n_df > 0) {
+        // hand-over to the one-launch kernel: what is still pending on every block column >= n_step (the pair of panels
+        // n_step-2, n_step-1 when the last launch was a paired one, else panel n_step-1) in one update-only launch (it
+        // also inverts diagonal block n_step-1)
+        const bool pair = n_step <= k_pair;
+        CholLaunch L = { -1, { -1, -1 }, { n_step - (pair ? 2 : 1), pair ? n_step - 1 : -1 }, n_step, 0, 0 };
+        L.t1 = pair ? (n_blk - L.c0 + 1) + update_tiles(n_blk, L.c0 - 1) : update_tiles(n_blk, L.c0 - 2);
+        out.push_back(L);
+    }
+    return out;
+}
+
+// tile t of a launch's update list (host copy of what the kernel computes)
+void chol_schedule_tile(int n_blk, const CholLaunch& L, int t, int* bi, int* bj)
+{
+    if (L.upd[1] >= 0)
+        pair_tile_index(n_blk, L.c0, t, *bi, *bj);
+    else
+        update_tile_index(n_blk, L.c0 - 2, t, *bi, *bj);
+}
+
 static void launch_dataflow(Engine& e, double* S, int n_pad, int ld, LmCtl* ctl, int first_blk, int n_blk)
 {
     DfArgs a;
@@ -2011,70 +2071,31 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
                            e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
         return;
     }
-    const int n_step = n_blk - n_df;   // block columns factored by one k_chol_step launch each (even when a tail follows)
-    // launches k < k_pair are paired (rank-128 updates), launch k_pair finishes the last pair alone, later ones are
-    // single (rank-64): measured at n = 6000, the pair wins while more than ~46 block columns are left
-    int k_pair = 0;
-    while (n_blk - k_pair > kPairMinBlocks)
-        k_pair += 2;
-    if (k_pair > n_step)
-        k_pair = n_step;       // (n_step is even when a tail follows, and then the hand-over finishes the last pair)
-    for (int k = 0; k < n_step; ++k) {
-        const int rows_below = n_pad + 1 - (k + 1) * kNB;
-        const int n_panel = 1 + (rows_below + 63) / 64;
-        int c0 = k + 1, t0 = 0, t1 = 0;
-        const double *PA = nullptr, *PB = nullptr, *Pprev2 = nullptr;
-        const double* const Pprev = k > 0 ? (const double*)e.P4[(k - 1) & 3] : (const double*)nullptr;
-        if (k >= 2 && k <= k_pair) {
-            // the pair of panels 2m-2, 2m-1 on the block columns >= c0 = 2m+1, shared by the launches 2m and 2m+1
-            // (launch k_pair: all of it)
-            const int m = k / 2;
-            c0 = 2 * m + 1;
-            PA = e.P4[(2 * m - 2) & 3];
-            PB = e.P4[(2 * m - 1) & 3];
-            if (!(k & 1))
-                Pprev2 = e.P4[(k - 2) & 3];
-            if (c0 <= n_blk - 1) {
-                const int n_first = n_blk - c0 + 1;
-                const int total = n_first + update_tiles(n_blk, c0 - 1);
-                const int half = k == k_pair ? total : std::max(n_first, (total + 1) / 2);
-                t0 = (k & 1) ? half : 0;
-                t1 = (k & 1) ? total : half;
-            }
-        } else if (k >= 1 && k > k_pair) {
-            PA = Pprev;                                  // panel k-1 on the block columns >= k+1
-            t1 = update_tiles(n_blk, k - 1);
+    for (const CholLaunch& L : chol_step_schedule(n_blk, n_df)) {
+        const int k = L.k >= 0 ? L.k : n_blk - n_df;   // (the hand-over launch carries the number of the first tail column)
+        int n_panel = 0;
+        if (L.k >= 0) {
+            const int rows_below = n_pad + 1 - (k + 1) * kNB;
+            n_panel = 1 + (rows_below + 63) / 64;
         }
-        const int n_upd = t1 - t0;
+        auto panel = [&](int p) { return p >= 0 ? (const double*)e.P4[p & 3] : (const double*)nullptr; };
+        const int n_upd = L.t1 - L.t0;
         // all workgroups of a launch resident at once (one per CU: 160 KB of LDS): the update workgroups
         // share the CUs the panel leaves free and loop over the tiles
-        const int n_upd_wg = std::min(n_upd, std::max(e.n_cu - n_panel - 1, e.n_cu / 4));
-        hipLaunchKernelGGL(k_chol_step, dim3(n_panel + n_upd_wg + (k > 0 ? 1 : 0)), dim3(256), 0, e.stream, ctl, S, ld,
-                           n_pad, n_blk, k, n_panel, e.P4[k & 3], Pprev, Pprev2, e.dinv, e.Ldiag, e.Linv, PA, PB, c0, t0,
-                           t1, n_upd_wg, e.flags + 258);
+        const int n_upd_wg = L.k >= 0 ? std::min(n_upd, std::max(e.n_cu - n_panel - 1, e.n_cu / 4))
+                                      : std::min(n_upd, e.n_cu - 1);
+        const int grid = n_panel + n_upd_wg + (k > 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_chol_step, dim3(grid), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, k, n_panel,
+                           L.k >= 0 ? e.P4[k & 3] : (double*)nullptr, panel(L.lazy[1]), panel(L.lazy[0]), e.dinv, e.Ldiag,
+                           e.Linv, panel(L.upd[0]), panel(L.upd[1]), L.c0, L.t0, L.t1, n_upd_wg, e.flags + 258);
         if (getenv("VMM_BA_DEBUG")) {
             const hipError_t le = hipPeekAtLastError();
             if (le != hipSuccess)
-                fprintf(stderr, "[vmm_ba debug] k_chol_step k=%d grid=%d: %s\n", k, n_panel + n_upd_wg + (k > 0 ? 1 : 0),
-                        hipGetErrorString(le));
+                fprintf(stderr, "[vmm_ba debug] k_chol_step k=%d grid=%d: %s\n", k, grid, hipGetErrorString(le));
         }
     }
-    if (n_df > 0) {
-        // hand-over to the one-launch kernel: what is still pending on every block column >= n_step (the pair of panels
-        // n_step-2, n_step-1 when the last launch was a paired one, else panel n_step-1) -- one update-only launch
-        // (with the inverse of diagonal block n_step-1), then the dataflow factorisation of the trailing n_df x n_df
-        // blocks (+ right-hand side row)
-        const bool pair = n_step <= k_pair;
-        const int c0 = n_step;
-        const int total = pair ? (n_blk - c0 + 1) + update_tiles(n_blk, c0 - 1) : update_tiles(n_blk, c0 - 2);
-        const int n_upd_wg = std::min(total, e.n_cu - 1);
-        hipLaunchKernelGGL(k_chol_step, dim3(n_upd_wg + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, n_step, 0,
-                           (double*)nullptr, (const double*)nullptr, (const double*)nullptr, e.dinv, e.Ldiag, e.Linv,
-                           (const double*)e.P4[(n_step - (pair ? 2 : 1)) & 3],
-                           pair ? (const double*)e.P4[(n_step - 1) & 3] : (const double*)nullptr, c0, 0, total, n_upd_wg,
-                           e.flags + 258);
-        launch_dataflow(e, S, n_pad, ld, ctl, n_step, n_blk);
-    }
+    if (n_df > 0)   // the trailing n_df x n_df blocks (+ right-hand side row) in one launch
+        launch_dataflow(e, S, n_pad, ld, ctl, n_blk - n_df, n_blk);
     // one chained launch while every workgroup of the chain is certainly resident (one per CU); the per-block
     // kernels otherwise
     if (chain) {

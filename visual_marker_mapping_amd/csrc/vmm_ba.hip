@@ -2216,6 +2216,40 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
 // back on one stream (today's order), (3) both at once on two streams -- the factorisation on a valid S, the rank-k
 // update of the same Z writing its sum into a scratch matrix, so that only the sharing of the chip is measured, not a
 // dependency; (4) the factorisation's own duration inside (3).  Dense elimination, one GPU.  ms[5] averages over reps.
+int vmm_ba_debug_chol_schedule(int n_blk, int n_df, int n_cu, int32_t* launches, int cap, int* n_launches, int* n_df_used)
+{
+    if (n_blk < 1 || n_cu < 1 || cap < 0 || (cap > 0 && !launches) || !n_launches || (n_df > 0 && n_df > n_blk - 2)) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    if (n_df < 0) {
+        n_df = dataflow_blocks(n_blk, n_cu);
+        if (n_df == n_blk)
+            n_df = 0;   // the one-launch kernel takes the whole system: what is returned is the fallback schedule
+    }
+    const std::vector<CholLaunch> sched = chol_step_schedule(n_blk, n_df);
+    for (size_t i = 0; i < sched.size() && (int)i < cap; ++i) {
+        const CholLaunch& L = sched[i];
+        const int32_t row[8] = { L.k, L.lazy[0], L.lazy[1], L.upd[0], L.upd[1], L.c0, L.t0, L.t1 };
+        memcpy(launches + 8 * i, row, sizeof(row));
+    }
+    *n_launches = (int)sched.size();
+    if (n_df_used)
+        *n_df_used = n_df;
+    return VMM_BA_OK;
+}
+
+int vmm_ba_debug_chol_tile(int n_blk, const int32_t* launch, int t, int* bi, int* bj)
+{
+    if (!launch || !bi || !bj || t < 0 || t >= launch[7]) {
+        set_error("bad argument");
+        return VMM_BA_ERR_ARGUMENT;
+    }
+    const CholLaunch L = { launch[0], { launch[1], launch[2] }, { launch[3], launch[4] }, launch[5], launch[6], launch[7] };
+    chol_schedule_tile(n_blk, L, t, bi, bj);
+    return VMM_BA_OK;
+}
+
 int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
 {
     if (!h || !ms || reps <= 0) {
