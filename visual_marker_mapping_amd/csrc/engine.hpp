@@ -185,6 +185,10 @@ struct Engine {
     int32_t* pair_terms = nullptr;  // [n_terms][2] position of the left block in the row's observation list | E-order
                                     // index of the right block (rhs pair: the eliminated pose)
     int32_t* row_items = nullptr;   // [2][n_row_items]
+    bool explicit_pairs = false;    // only the pairs that share an eliminated pose are listed (pair_col), S zero-filled first
+    int32_t* pair_col = nullptr;    // [n_pairs] first column of the pair's block in S (-1: the row's right-hand side entry)
+    int32_t* row_of = nullptr;      // [n_f] first row of every kept pose in the reduced system (explicit form only)
+    std::vector<int32_t> h_row_of;  // host copy; empty: kept pose f sits at row 6 f
     int n_row_items = 0;
     double schur_flops = 0.0;       // algorithmic flops of the reduced-system formation on the path in use
     SyrkPlan syrk;                  // stream-K plan of S = Z^T Z

@@ -487,7 +487,8 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
                                                  const int32_t* __restrict__ active,
                                                  double* __restrict__ pose_part,
                                                  const int32_t* __restrict__ e_start,
-                                                 const int32_t* __restrict__ e_other)
+                                                 const int32_t* __restrict__ e_other,
+                                                 const int32_t* __restrict__ row_of)
 {
     // world > 1: this rank's vote on "the factorisation of this pass gave up waiting" rides on the step all-reduce
     // (slot 7 n_e, behind the steps and the per-pose cross terms), so that all ranks pause in the same pass (k_candidate)
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
         double d[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            d[k] = lin_fail ? 0.0 : -yf[6 * (int64_t)f + k] * scale[6 * (int64_t)p + k];
+            d[k] = lin_fail ? 0.0 : -yf[(row_of ? row_of[f] : 6 * f) + k] * scale[6 * (int64_t)p + k];
         candidate_for_pose(pv, p, d, delta, H, g, active, pose_part);
         return;
     }
@@ -539,7 +540,8 @@ __global__ __launch_bounds__(256) void k_backsub(const LmCtl* ctl, int n_e, int 
         const double* zp = Z + 36 * (int64_t)es;   // the pose's blocks: [observation][6][6]
         for (int t = (int)threadIdx.x; t < rs; t += 256) {
             const int k = t / 6, c = t - 6 * k;
-            const double yv = yf[6 * (int64_t)e_other[es + k] + c];
+            const int fo = e_other[es + k];
+            const double yv = yf[(row_of ? row_of[fo] : 6 * fo) + c];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
                 acc[i] += zp[36 * k + 6 * c + i] * yv;   // Z(i, c) of block k, column-major
@@ -605,7 +607,8 @@ __global__ void k_candidate(LmCtl* ctl, PoseViews pv, int n_e, int e_off_pose, i
                             const double* __restrict__ step_comm, const double* __restrict__ yf,
                             const double* __restrict__ scale, double* __restrict__ delta,
                             const double* __restrict__ H, const double* __restrict__ g,
-                            const int32_t* __restrict__ active, double* __restrict__ pose_part)
+                            const int32_t* __restrict__ active, double* __restrict__ pose_part,
+                            const int32_t* __restrict__ row_of)
 {
     // the summed votes of k_backsub: some rank's factorisation gave up waiting in this pass -> every rank pauses here
     // (the ranks must take the same decisions and make the same collective calls; the hosts redo the pass together)
@@ -629,7 +632,7 @@ __global__ void k_candidate(LmCtl* ctl, PoseViews pv, int n_e, int e_off_pose, i
         else if (is_e)
             d[k] = step_comm[6 * (int64_t)(p - e_off_pose) + k];
         else
-            d[k] = -yf[6 * (int64_t)(p - f_off_pose) + k] * scale[6 * (int64_t)p + k];
+            d[k] = -yf[(row_of ? row_of[p - f_off_pose] : 6 * (p - f_off_pose)) + k] * scale[6 * (int64_t)p + k];
     }
     candidate_for_pose(pv, p, d, delta, H, g, active, pose_part);
 }
@@ -747,7 +750,8 @@ void launch_backsub(Engine& e)
     hipLaunchKernelGGL((k_backsub<FUSE, SP>), dim3(GRID), dim3(256), 0, e.stream, e.ctl, e.n_e, e_off, e.ordE.pose_task,   \
                        Zp, e.ldz, e.n_red, e.yf, e.Le, e.ze, e.scale, e.step_comm, crossp, views(e), f_off, e.n_f,        \
                        nb_e, e.delta, e.H_cam, e.g_cam, e.small_alt_off, e.active, e.pose_part,                           \
-                       (const int32_t*)e.ordE.start, (const int32_t*)e.ordE.other)
+                       (const int32_t*)e.ordE.start, (const int32_t*)e.ordE.other,                                         \
+                       (const int32_t*)((e.sparse_schur && e.explicit_pairs) ? e.row_of : nullptr))
     if (e.multi) {
         if (e.sparse_schur)
             VMM_BACKSUB(false, true, nb_e);
@@ -771,7 +775,8 @@ void launch_candidate(Engine& e)
     const int f_off = e.elim_cams ? e.n_cams : 0;
     const int n_pose = e.n_cams + e.n_tags;
     hipLaunchKernelGGL(k_candidate, dim3((n_pose + 63) / 64), dim3(64), 0, e.stream, e.ctl, views(e), e.n_e, e_off,
-                       f_off, e.step_comm, e.yf, e.scale, e.delta, e.H_cam, e.g_cam, e.active, e.pose_part);
+                       f_off, e.step_comm, e.yf, e.scale, e.delta, e.H_cam, e.g_cam, e.active, e.pose_part,
+                       (const int32_t*)((e.sparse_schur && e.explicit_pairs) ? e.row_of : nullptr));
 }
 
 // Touches every kernel of this file once (vmm_ba_create): the code object is loaded and the kernel's resources

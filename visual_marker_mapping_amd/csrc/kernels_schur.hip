@@ -405,6 +405,8 @@ struct PairArgs {
     int ld, n_items, n_f;
     DiagArgs da;
     int add_diag;
+    const int32_t* pair_col;    // explicit form: [n_pairs] first column of the pair's block (-1: right-hand side); else null
+    const int32_t* row_of;      // explicit form: [n_f] first row of kept pose f in S
 };
 
 #ifndef VMM_PAIR_NS
@@ -451,9 +453,12 @@ __global__ __launch_bounds__(kPairThreads) void k_schur_pairs(PairArgs a)
     const int row_p0 = a.pair_start[f];
     const int sl = tid % kPairSplit;               // which of the pair's term subsequences
     const int p = a.item_p0[blockIdx.x] + tid / (6 * kPairSplit), c = (tid / kPairSplit) % 6;
-    const int j = p - row_p0;                      // f' (0..f) or f + 1: the right-hand side
-    const bool valid = tid < 6 * kPairSplit * kPairsPerItem && j <= f + 1;
-    const bool rhs = j == f + 1;
+    const int j = p - row_p0;                      // implicit form: f' (0..f) or f + 1: the right-hand side
+    const bool expl = a.pair_col != nullptr;
+    const bool valid = tid < 6 * kPairSplit * kPairsPerItem && (expl ? p < a.pair_start[f + 1] : j <= f + 1);
+    const int rbase = expl ? a.row_of[f] : 6 * f;                    // first row of f's blocks in S
+    const int cbase = expl ? (valid ? a.pair_col[p] : 0) : 6 * j;    // first column of this pair's block
+    const bool rhs = expl ? cbase < 0 : j == f + 1;
     int t = valid ? a.tstart[p] + sl : 0;
     const int t1 = valid ? a.tstart[p + 1] : 0;
     const int fs = a.f_start[f], len = a.f_start[f + 1] - fs;
@@ -564,25 +569,48 @@ __global__ __launch_bounds__(kPairThreads) void k_schur_pairs(PairArgs a)
         a.da.H_F += small_sel(a.ctl, a.da.alt_off);
         a.da.g_F += small_sel(a.ctl, a.da.alt_off);
     }
+    // (scale_F, g_F, D2_F, H_F are indexed by the kept pose's parameter number 6 f + q; S by its row rbase + q)
     if (rhs) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            const int col = 6 * f + q;
-            a.S[(int64_t)n_pad * ld + col] = (a.add_diag ? a.da.scale_F[col] * a.da.g_F[col] : 0.0) - acc[q];
+            const int par = 6 * f + q;
+            a.S[(int64_t)n_pad * ld + rbase + q] = (a.add_diag ? a.da.scale_F[par] * a.da.g_F[par] : 0.0) - acc[q];
         }
         return;
     }
-    const int gcol = 6 * j + c;
+    const bool diag_pair = cbase == rbase;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-        const int row = 6 * f + q;
+        const int par = 6 * f + q;
         double v = -acc[q];
-        if (a.add_diag && j == f) {
-            v += a.da.scale_F[row] * a.da.H_F[36 * (int64_t)f + 6 * q + c] * a.da.scale_F[gcol];
+        if (a.add_diag && diag_pair) {
+            v += a.da.scale_F[par] * a.da.H_F[36 * (int64_t)f + 6 * q + c] * a.da.scale_F[6 * f + c];
             if (q == c)
-                v += a.da.D2_F[row];
+                v += a.da.D2_F[par];
         }
-        a.S[(int64_t)row * ld + gcol] = v;
+        a.S[(int64_t)(rbase + q) * ld + cbase + c] = v;
+    }
+}
+
+// Explicit pair lists write only the blocks that exist: everything else the factorisation reads -- the lower block
+// triangle up to the end of each row's diagonal 64-block, the right-hand side row -- is zeroed first, with a unit diagonal
+// (one GPU; the pairs overwrite it on the rows of kept poses, it stays on the padding rows).
+__global__ __launch_bounds__(256) void k_fill_lower(const LmCtl* ctl, double* __restrict__ S, int ld, int n_pad, int unit_diag)
+{
+    if (ctl && ctl->done)
+        return;
+    const int row = blockIdx.x;   // 0 .. n_pad
+    const int c1 = row == n_pad ? n_pad : (row / 64) * 64 + 64;
+    double2* __restrict__ dst = reinterpret_cast<double2*>(S + (int64_t)row * ld);
+    for (int j = threadIdx.x; 2 * j < c1; j += 256) {
+        double2 v = make_double2(0.0, 0.0);
+        if (unit_diag && row < n_pad) {
+            if (2 * j == row)
+                v.x = 1.0;
+            if (2 * j + 1 == row)
+                v.y = 1.0;
+        }
+        dst[j] = v;
     }
 }
 
@@ -676,7 +704,13 @@ void launch_schur_rows(Engine& e, bool add_diag)
     a.da.n_pad = e.n_pad;
     a.da.alt_off = e.small_alt_off;
     a.add_diag = add_diag ? 1 : 0;
-    const int n_fill = std::min(64, e.n_pad + 1);   // workgroups for the rows' zero fill and the padding
+    a.pair_col = e.explicit_pairs ? e.pair_col : nullptr;   // (launch_schur_rows only runs on the block-sparse path)
+    a.row_of = e.explicit_pairs ? e.row_of : nullptr;
+    if (e.explicit_pairs)
+        hipLaunchKernelGGL(k_fill_lower, dim3(e.n_pad + 1), dim3(256), 0, e.stream, (const LmCtl*)e.ctl, e.S, e.ldz, e.n_pad,
+                           add_diag ? 1 : 0);
+    // implicit form: extra workgroups for the rows' zero fill and the padding
+    const int n_fill = e.explicit_pairs ? 0 : std::min(64, e.n_pad + 1);
     hipLaunchKernelGGL(k_schur_pairs, dim3(e.n_row_items + n_fill), dim3(kPairThreads), 0, e.stream, a);
 }
 
@@ -800,6 +834,7 @@ int preload_schur_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<double, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_form_z<float, true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_schur_pairs)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_fill_lower)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_syrk_streamk)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<false>)) != hipSuccess;

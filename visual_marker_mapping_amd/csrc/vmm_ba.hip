@@ -1231,19 +1231,76 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         // A term of pair (f, f') = two observations (e, f), (e, f') of one eliminated pose; terms are listed in e
         // order (that is the summation order), the left block by its position in f's row (the kernel stages the
         // row's blocks in LDS), the right block by its E-order index.
-        std::vector<int32_t> pstart((size_t)e.n_f + 1, 0);
+        // Two forms of the pair list.  Implicit (every pair of the lower triangle, the empty ones written as zeros:
+        // pair j of row f is f' = j): visibility-type scenes, where nearly every pair exists.  Explicit (only the pairs
+        // that share an eliminated pose, their column in `pair_col`; S is zero-filled by a kernel of its own first):
+        // scenes where an image sees a handful of tags -- at 6-10 tags per image 3.4 k of the 20.1 k pairs exist.  The
+        // explicit form also carries the position of every kept pose in the reduced system (`row_of`), which need not
+        // be 6 f (tree orderings of the kept family).
+        std::vector<int32_t> rank_of((size_t)e.n_f);                  // order of the kept poses in the reduced system
         for (int fq = 0; fq < e.n_f; ++fq)
-            pstart[(size_t)fq + 1] = pstart[(size_t)fq] + fq + 2;
+            rank_of[(size_t)fq] = e.h_row_of.empty() ? fq : e.h_row_of[(size_t)fq];
+        std::vector<std::vector<int32_t>> partners;                    // explicit form: f' of every pair of row f
+        {
+            double co = 0.0;   // co-observed pairs incl. the diagonal, counted once
+            std::vector<int32_t> mark((size_t)e.n_f, -1);
+            std::vector<std::vector<int32_t>> adj((size_t)e.n_f);
+            for (int q = 0; q < e.n_e; ++q)
+                for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1)
+                    for (int32_t d2 = startE[q]; d2 < startE[q + 1]; ++d2) {
+                        const int f1 = otherE[(size_t)d1], f2 = otherE[(size_t)d2];
+                        if (rank_of[(size_t)f2] < rank_of[(size_t)f1])
+                            adj[(size_t)f1].push_back(f2);
+                    }
+            for (int fq = 0; fq < e.n_f; ++fq) {
+                std::vector<int32_t>& a = adj[(size_t)fq];
+                std::sort(a.begin(), a.end(), [&](int32_t x, int32_t y) { return rank_of[(size_t)x] < rank_of[(size_t)y]; });
+                a.erase(std::unique(a.begin(), a.end()), a.end());
+                a.push_back(fq);   // the diagonal pair: always there (it carries the kept pose's own block)
+                co += (double)a.size();
+            }
+            const double all = 0.5 * (double)e.n_f * (e.n_f + 1.0);
+            e.explicit_pairs = !e.h_row_of.empty() || co < 0.5 * all;
+            if (const char* pv = getenv("VMM_BA_PAIRS"))
+                e.explicit_pairs = !e.h_row_of.empty() || !strcmp(pv, "explicit");
+            if (e.explicit_pairs)
+                partners.swap(adj);
+            (void)mark;
+        }
+        std::vector<int32_t> pstart((size_t)e.n_f + 1, 0), pcol;
+        for (int fq = 0; fq < e.n_f; ++fq)
+            pstart[(size_t)fq + 1] = pstart[(size_t)fq] + (e.explicit_pairs ? (int32_t)partners[(size_t)fq].size() + 1 : fq + 2);
         const size_t n_pairs = (size_t)pstart[(size_t)e.n_f];
+        // pair id of (f1, f2) inside row f1; explicit form: through a per-row look-up table
+        std::vector<int32_t> slot_of;
+        if (e.explicit_pairs) {
+            pcol.assign(n_pairs, -1);
+            for (int fq = 0; fq < e.n_f; ++fq)
+                for (size_t k = 0; k < partners[(size_t)fq].size(); ++k)
+                    pcol[(size_t)pstart[(size_t)fq] + k] = e.h_row_of.empty() ? 6 * partners[(size_t)fq][k]
+                                                                              : e.h_row_of[(size_t)partners[(size_t)fq][k]];
+        }
+        // (f1, f2) -> pair id or -1.  Explicit: binary search in row f1's partner list (sorted by rank).
+        auto pair_id = [&](int f1, int f2) -> int64_t {
+            if (!e.explicit_pairs)
+                return f2 <= f1 ? (int64_t)pstart[(size_t)f1] + f2 : -1;
+            if (rank_of[(size_t)f2] > rank_of[(size_t)f1])
+                return -1;
+            const std::vector<int32_t>& a = partners[(size_t)f1];
+            const auto it = std::lower_bound(a.begin(), a.end(), f2,
+                                             [&](int32_t x, int32_t y) { return rank_of[(size_t)x] < rank_of[(size_t)y]; });
+            return (int64_t)pstart[(size_t)f1] + (it - a.begin());
+        };
+        auto rhs_id = [&](int f1) -> int64_t { return (int64_t)pstart[(size_t)f1 + 1] - 1; };
         std::vector<int32_t> tstart(n_pairs + 1, 0);
         for (int q = 0; q < e.n_e; ++q)
             for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1) {
                 const int f1 = otherE[(size_t)d1];
-                tstart[(size_t)pstart[(size_t)f1] + f1 + 1 + 1]++;   // rhs pair of row f1
+                tstart[(size_t)rhs_id(f1) + 1]++;   // rhs pair of row f1
                 for (int32_t d2 = startE[q]; d2 < startE[q + 1]; ++d2) {
-                    const int f2 = otherE[(size_t)d2];
-                    if (f2 <= f1)
-                        tstart[(size_t)pstart[(size_t)f1] + f2 + 1]++;
+                    const int64_t id = pair_id(f1, otherE[(size_t)d2]);
+                    if (id >= 0)
+                        tstart[(size_t)id + 1]++;
                 }
             }
         for (size_t k = 0; k < n_pairs; ++k)
@@ -1258,15 +1315,15 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
             for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1) {
                 const int f1 = otherE[(size_t)d1];
                 {
-                    const int32_t k = fill[(size_t)pstart[(size_t)f1] + f1 + 1]++;
+                    const int32_t k = fill[(size_t)rhs_id(f1)]++;
                     ta[(size_t)k] = row_pos[(size_t)d1];
                     tb[(size_t)k] = q;
                 }
                 for (int32_t d2 = startE[q]; d2 < startE[q + 1]; ++d2) {
-                    const int f2 = otherE[(size_t)d2];
-                    if (f2 > f1)
+                    const int64_t id = pair_id(f1, otherE[(size_t)d2]);
+                    if (id < 0)
                         continue;
-                    const int32_t k = fill[(size_t)pstart[(size_t)f1] + f2]++;
+                    const int32_t k = fill[(size_t)id]++;
                     ta[(size_t)k] = row_pos[(size_t)d1];
                     tb[(size_t)k] = d2;
                 }
@@ -1293,8 +1350,15 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         // work items: up to pairs_per_item() consecutive pairs of one row; rows with many pairs first
         std::vector<int32_t> item_row, item_p0;
         const int ppi = schur_pairs_per_item();
-        for (int fq = e.n_f - 1; fq >= 0; --fq)
-            for (int j0 = 0; j0 < fq + 2; j0 += ppi) {
+        std::vector<int32_t> rows_by_len((size_t)e.n_f);
+        for (int fq = 0; fq < e.n_f; ++fq)
+            rows_by_len[(size_t)fq] = e.n_f - 1 - fq;
+        if (e.explicit_pairs)
+            std::stable_sort(rows_by_len.begin(), rows_by_len.end(), [&](int32_t x, int32_t y) {
+                return pstart[(size_t)x + 1] - pstart[(size_t)x] > pstart[(size_t)y + 1] - pstart[(size_t)y];
+            });
+        for (const int32_t fq : rows_by_len)
+            for (int j0 = 0; j0 < pstart[(size_t)fq + 1] - pstart[(size_t)fq]; j0 += ppi) {
                 item_row.push_back(fq);
                 item_p0.push_back(pstart[(size_t)fq] + j0);
             }
@@ -1316,6 +1380,15 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         if ((rc = upload(e, e.pair_tstart, tstart))) return fail(rc);
         if ((rc = upload(e, e.pair_terms, tt))) return fail(rc);
         if ((rc = upload(e, e.row_items, items))) return fail(rc);
+        if (e.explicit_pairs) {
+            std::vector<int32_t> rows((size_t)e.n_f);
+            for (int fq = 0; fq < e.n_f; ++fq)
+                rows[(size_t)fq] = e.h_row_of.empty() ? 6 * fq : e.h_row_of[(size_t)fq];
+            if ((rc = dev_alloc(e, &e.pair_col, pcol.size()))) return fail(rc);
+            if ((rc = dev_alloc(e, &e.row_of, rows.size()))) return fail(rc);
+            if ((rc = upload(e, e.pair_col, pcol))) return fail(rc);
+            if ((rc = upload(e, e.row_of, rows))) return fail(rc);
+        }
         if (hipStreamSynchronize(e.stream) != hipSuccess) {   // host vectors go out of scope
             set_error("create: upload of the block-sparse plan failed");
             return fail(VMM_BA_ERR_HIP);
