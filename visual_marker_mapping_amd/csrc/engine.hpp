@@ -189,6 +189,7 @@ struct Engine {
     int32_t* pair_col = nullptr;    // [n_pairs] first column of the pair's block in S (-1: the row's right-hand side entry)
     int32_t* row_of = nullptr;      // [n_f] first row of every kept pose in the reduced system (explicit form only)
     std::vector<int32_t> h_row_of;  // host copy; empty: kept pose f sits at row 6 f
+    std::vector<int32_t> nd_node_first_blk;   // tree ordering: first 64-row block of every node, in elimination order
     int n_row_items = 0;
     double schur_flops = 0.0;       // algorithmic flops of the reduced-system formation on the path in use
     SyrkPlan syrk;                  // stream-K plan of S = Z^T Z

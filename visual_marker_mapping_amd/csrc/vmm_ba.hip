@@ -890,6 +890,101 @@ void vmm_ba_default_create_options(vmm_ba_create_options* o)
     o->world_size = 1;
 }
 
+// ---- tree ordering of the kept family (block-sparse path) -------------------------------------------------------
+// Nested dissection of the co-observation graph of the kept poses (two kept poses are neighbours when one eliminated
+// pose sees both: exactly the non-zero blocks of the reduced system).  A part is cut at the breadth-first level (from a
+// pseudo-peripheral vertex) that balances the two sides; the level is the separator and is ordered BEHIND both sides,
+// recursively.  `nodes` comes out in elimination order (children before their separator); parts of one level do not
+// touch each other, so their block columns of the factor do not depend on each other.
+static void nd_dissect(const std::vector<std::vector<int32_t>>& nbr, std::vector<int32_t> verts, int leaf_max, int depth,
+                       std::vector<int32_t>& stamp, int32_t& stamp_next, std::vector<std::vector<int32_t>>& nodes)
+{
+    if (verts.empty())
+        return;
+    if ((int)verts.size() <= leaf_max || depth <= 0) {
+        nodes.push_back(std::move(verts));
+        return;
+    }
+    // connected components of the induced subgraph
+    const int32_t in_set = stamp_next++;
+    for (const int32_t v : verts)
+        stamp[(size_t)v] = in_set;
+    std::vector<std::vector<int32_t>> comps;
+    {
+        const int32_t seen = stamp_next++;
+        for (const int32_t v0 : verts) {
+            if (stamp[(size_t)v0] != in_set)
+                continue;
+            comps.emplace_back();
+            std::vector<int32_t>& c = comps.back();
+            c.push_back(v0);
+            stamp[(size_t)v0] = seen;
+            for (size_t h = 0; h < c.size(); ++h)
+                for (const int32_t w : nbr[(size_t)c[h]])
+                    if (stamp[(size_t)w] == in_set) {
+                        stamp[(size_t)w] = seen;
+                        c.push_back(w);
+                    }
+        }
+    }
+    if (comps.size() > 1) {
+        // independent already: two groups of about equal size, no separator
+        std::sort(comps.begin(), comps.end(),
+                  [](const std::vector<int32_t>& a, const std::vector<int32_t>& b) { return a.size() > b.size(); });
+        std::vector<int32_t> A, B;
+        for (auto& c : comps) {
+            std::vector<int32_t>& dst = A.size() <= B.size() ? A : B;
+            dst.insert(dst.end(), c.begin(), c.end());
+        }
+        nd_dissect(nbr, std::move(A), leaf_max, depth - 1, stamp, stamp_next, nodes);
+        nd_dissect(nbr, std::move(B), leaf_max, depth - 1, stamp, stamp_next, nodes);
+        return;
+    }
+    // level structure from a pseudo-peripheral vertex (two sweeps)
+    std::vector<int32_t> order, level_of_pos;
+    int32_t root = verts[0];
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        const int32_t mark = stamp_next++, todo = stamp_next++;
+        for (const int32_t v : verts)
+            stamp[(size_t)v] = todo;
+        order.assign(1, root);
+        level_of_pos.assign(1, 0);
+        stamp[(size_t)root] = mark;
+        for (size_t h = 0; h < order.size(); ++h)
+            for (const int32_t w : nbr[(size_t)order[h]])
+                if (stamp[(size_t)w] == todo) {
+                    stamp[(size_t)w] = mark;
+                    order.push_back(w);
+                    level_of_pos.push_back(level_of_pos[h] + 1);
+                }
+        root = order.back();
+    }
+    const int n_levels = level_of_pos.back() + 1;
+    if (n_levels < 3) {   // (nearly) complete graph: nothing to cut
+        nodes.push_back(std::move(verts));
+        return;
+    }
+    std::vector<int32_t> cnt((size_t)n_levels, 0);
+    for (const int32_t l : level_of_pos)
+        cnt[(size_t)l]++;
+    int best = 1;
+    long long best_cost = -1;
+    for (int l = 1, below = cnt[0]; l + 1 < n_levels; below += cnt[(size_t)l], ++l) {
+        const int above = (int)order.size() - below - cnt[(size_t)l];
+        const long long cost = (long long)std::abs(below - above) * 4 + cnt[(size_t)l];
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = l;
+        }
+    }
+    std::vector<int32_t> A, B, S;
+    for (size_t h = 0; h < order.size(); ++h)
+        (level_of_pos[h] < best ? A : level_of_pos[h] > best ? B : S).push_back(order[h]);
+    nd_dissect(nbr, std::move(A), leaf_max, depth - 1, stamp, stamp_next, nodes);
+    nd_dissect(nbr, std::move(B), leaf_max, depth - 1, stamp, stamp_next, nodes);
+    nodes.push_back(std::move(S));
+}
+
 int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vmm_ba_handle* out)
 {
     if (!p || !out) {
@@ -1214,6 +1309,59 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
                 e.sparse_schur = e.n_obs > 0;
         }
         e.schur_flops = e.sparse_schur ? sparse_flops : dense_flops;
+    }
+    // Tree ordering of the kept family (VMM_BA_ORDER=nd; one GPU, block-sparse path): every node of the dissection tree
+    // starts on a 64-row boundary of the reduced system (padding rows with a unit diagonal in between), so that whole
+    // block columns of the factor belong to one node and the block columns of two parts of one level are independent.
+    {
+        const char* ov = getenv("VMM_BA_ORDER");
+        if (e.sparse_schur && !e.multi && ov && !strcmp(ov, "nd") && e.n_f > 1) {
+            std::vector<std::vector<int32_t>> nbr((size_t)e.n_f);
+            for (int q = 0; q < e.n_e; ++q)
+                for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1)
+                    for (int32_t d2 = startE[q]; d2 < startE[q + 1]; ++d2)
+                        if (d1 != d2)
+                            nbr[(size_t)otherE[(size_t)d1]].push_back(otherE[(size_t)d2]);
+            for (auto& v : nbr) {
+                std::sort(v.begin(), v.end());
+                v.erase(std::unique(v.begin(), v.end()), v.end());
+            }
+            std::vector<int32_t> all((size_t)e.n_f), stamp((size_t)e.n_f, 0);
+            for (int fq = 0; fq < e.n_f; ++fq)
+                all[(size_t)fq] = fq;
+            int32_t stamp_next = 1;
+            int leaf_max = 21;   // tags per leaf: two 64-row blocks
+            if (const char* lv = getenv("VMM_BA_ND_LEAF"))
+                leaf_max = std::max(1, atoi(lv));
+            std::vector<std::vector<int32_t>> nodes;
+            nd_dissect(nbr, all, leaf_max, 12, stamp, stamp_next, nodes);
+            std::vector<int32_t> rows((size_t)e.n_f, -1);
+            int row = 0;
+            for (const auto& nd : nodes) {
+                row = round_up(row, kNB);
+                for (const int32_t v : nd) {
+                    rows[(size_t)v] = row;
+                    row += 6;
+                }
+            }
+            const int n_pad_nd = round_up(row, kNB);
+            if (nodes.size() > 2 && dataflow_workgroups(n_pad_nd / kNB) <= dataflow_max_workgroups(e.n_cu)) {
+                e.h_row_of = rows;
+                e.nd_node_first_blk.clear();
+                int r2 = 0;
+                for (const auto& nd : nodes) {
+                    r2 = round_up(r2, kNB);
+                    e.nd_node_first_blk.push_back(r2 / kNB);
+                    r2 += 6 * (int)nd.size();
+                }
+                e.n_pad = n_pad_nd;
+                e.n_blk = e.n_pad / kNB;
+                e.ldz = round_up(e.n_pad + 1, kST) + 32;
+                if (getenv("VMM_BA_DEBUG"))
+                    fprintf(stderr, "[vmm_ba debug] tree ordering: %zu nodes, %d rows (%d blocks) for %d kept poses\n",
+                            nodes.size(), e.n_pad, e.n_blk, e.n_f);
+            }
+        }
     }
     if (e.sparse_schur) {
         if ((rc = dev_alloc(e, &e.Zc, (size_t)36 * std::max<int64_t>(e.n_obs, 1)))) return fail(rc);
