@@ -189,6 +189,9 @@ struct Engine {
     int32_t* pair_col = nullptr;    // [n_pairs] first column of the pair's block in S (-1: the row's right-hand side entry)
     int32_t* row_of = nullptr;      // [n_f] first row of every kept pose in the reduced system (explicit form only)
     std::vector<int32_t> h_row_of;  // host copy; empty: kept pose f sits at row 6 f
+    unsigned long long* chol_nz = nullptr;    // [n_blk + 1] block structure of the factor (tree ordering), see DfArgs::nz
+    unsigned char* chol_order = nullptr;      // [n_blk][64] panel order per block column, see DfArgs::order
+    bool chol_nz_on = false;                  // off while a call factors the dense, naturally ordered system (covariance)
     std::vector<int32_t> nd_node_first_blk;   // tree ordering: first 64-row block of every node, in elimination order
     int n_row_items = 0;
     double schur_flops = 0.0;       // algorithmic flops of the reduced-system formation on the path in use

@@ -939,6 +939,17 @@ __device__ __forceinline__ void raise_sync_timeout(LmCtl* ctl, int bit)
 
 int backsolve_chain_workgroups(int n_blk) { return n_blk; }
 
+// The workgroup that finishes LAST retires the epoch (every workgroup has read the old value at its start by then; with
+// a tree ordering block 0 is not the last to finish any more) and leaves the counter at zero for the next launch.
+__device__ __forceinline__ void chain_block_done(unsigned* n_done, int n_blk, unsigned* epoch_word, unsigned epoch)
+{
+    __threadfence();
+    if (atomicAdd(n_done, 1u) == (unsigned)n_blk - 1u) {
+        *n_done = 0u;
+        *epoch_word = epoch;
+    }
+}
+
 #ifdef VMM_STAMPS
 __device__ unsigned long long g_chain_stamps[128][4];   // [block]: start, last dependency seen, published
 #define CH_RT(blk, slot)                                                                  \
@@ -958,7 +969,8 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
                                                          int n_pad, int n_blk, double* y,
                                                          const double* __restrict__ dinv, unsigned long long* gran,
                                                          unsigned* epoch_word, const double* __restrict__ Ld,
-                                                         const double* __restrict__ Linv)
+                                                         const double* __restrict__ Linv,
+                                                         const unsigned long long* __restrict__ nz, unsigned* n_done)
 {
     // (a give-up inside the dataflow factorisation before this launch has set done = 2: a workgroup that stops
     // waiting poisons and still publishes, so the factorisation's last workgroup ends after every give-up and sees
@@ -966,8 +978,8 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     if (ctl->done || ctl->lin_fail) {
         // the factorisation before this launch may have tagged granules with the current epoch: retire it even
         // when the solve is skipped (every workgroup of this launch leaves here, so nobody needs the old value)
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-            *epoch_word = *epoch_word + 1u;
+        if (threadIdx.x == 0)
+            chain_block_done(n_done, n_blk, epoch_word, *epoch_word + 1u);
         return;
     }
     const unsigned spin_limit = ctl->spin_limit_chain ? ctl->spin_limit_chain : kSpinLimit;
@@ -1039,17 +1051,26 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
             publish(yv);
         }
         CH_RT(m, 2);
-        if (tid == 0 && m == 0)
-            *epoch_word = epoch;   // a single block: also the end of the chain
+        if (tid == 0)
+            chain_block_done(n_done, n_blk, epoch_word, epoch);
         return;   // no wait, so no timeout
     }
-    // ---- B_m = L(m+1, m) Linv_m on the matrix cores: wave `part` computes rows part*16 .. part*16+15 ----
+    // The blocks of column m below the diagonal.  Dense: all of m+1 .. n_blk-1, and the hop waits for y_{m+1}.  With the
+    // factor's block structure (tree ordering): only those with L(j, m) != 0; the nearest one, jp, is the block whose
+    // unknowns arrive last (the parent in the elimination tree) and takes the place of m+1; without any, y_m = u_m.
+    // (nz is only given for systems of at most 48 blocks: m < 64)
+    auto below = [&](int jj) { return !nz || ((nz[jj] >> m) & 1ull); };   // L(jj, m) may be non-zero
+    int jp = m + 1;
+    while (jp < n_blk && !below(jp))
+        ++jp;
+    const bool has_parent = jp < n_blk;
+    // ---- B_m = L(jp, m) Linv_m on the matrix cores: wave `part` computes rows part*16 .. part*16+15 ----
     // (as 16 x 64 dot products per thread with broadcast LDS reads it took 15 us: every workgroup was late for its hop)
     double li[16];
     {
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int r = idx >> 6, cc = idx & 63;
-            L[r * kLd + cc] = S[(int64_t)((m + 1) * kNB + r) * ld + K0 + cc];
+            L[r * kLd + cc] = has_parent ? S[(int64_t)(jp * kNB + r) * ld + K0 + cc] : 0.0;
             Li[r * kLd + cc] = Linv[(int64_t)m * 4096 + r * 64 + cc];   // lower triangular, zero above the diagonal
         }
         __syncthreads();
@@ -1079,32 +1100,40 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
                 sB[fk + 4 * r][part * 64 + 16 * t + fi] = accB[t][r];
         __syncthreads();
     }
-    // ---- the blocks behind m+1: acc = sum_j L(j, m)^T y_j ----
+    // ---- the blocks behind jp: acc = sum_j L(j, m)^T y_j, highest block first ----
     double acc = 0.0;
     double lt[16], ln[16];
-    int j = n_blk - 1;
-    if (j > m + 1) {
+    auto next_down = [&](int from) {   // the highest block below `from` (exclusive) and above jp with an entry; jp: none
+        int jj = from - 1;
+        while (jj > jp && !below(jj))
+            --jj;
+        return jj;
+    };
+    int j = has_parent ? next_down(n_blk) : jp;
+    if (j > jp) {
         const double* Lb = S + (int64_t)(j * kNB + part * 16) * ld + K0 + c;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             lt[r] = Lb[(int64_t)r * ld];
     }
-    for (; j > m + 1; --j) {
-        if (j - 1 > m + 1) {   // next tile requested before the wait
-            const double* Lb = S + (int64_t)((j - 1) * kNB + part * 16) * ld + K0 + c;
+    for (int parity = 0; j > jp; parity ^= 1) {
+        const int jn = next_down(j);
+        if (jn > jp) {   // next tile requested before the wait
+            const double* Lb = S + (int64_t)(jn * kNB + part * 16) * ld + K0 + c;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 ln[r] = Lb[(int64_t)r * ld];
         }
-        double* ysj = ys[j & 1];
+        double* ysj = ys[parity];
         receive(j, ysj);
-        __syncthreads();   // also orders the reuse of ys[j & 1] two hops later
+        __syncthreads();   // also orders the reuse of ys[parity] two blocks later
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             acc += lt[r] * ysj[part * 16 + r];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             lt[r] = ln[r];
+        j = jn;
     }
     // ---- u_m = Linv_m^T (w_m - acc): one hop ahead of the value it will be combined with ----
     red[part][c] = acc;
@@ -1122,9 +1151,12 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     double u = 0.0;
     if (part == 0)
         u = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    // ---- the hop: y_m = u_m - B_m^T y_{m+1} ----
-    double* ysj = ys[(m + 1) & 1];
-    receive(m + 1, ysj);
+    // ---- the hop: y_m = u_m - B_m^T y_jp ----
+    double* ysj = ys[0];   // (every earlier use of ys[] is behind the barriers above)
+    if (has_parent)
+        receive(jp, ysj);
+    else if (part == 0)
+        ysj[c] = 0.0;
     __syncthreads();   // also: everyone has read red[] above
     CH_RT(m, 1);
     double a3 = 0.0;
@@ -1139,8 +1171,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     if (tid == 0) {
         if (s_timeout)
             raise_sync_timeout(ctl, 2);
-        if (m == 0)
-            *epoch_word = epoch;   // block 0 is the end of the chain: every other workgroup has read the old value
+        chain_block_done(n_done, n_blk, epoch_word, epoch);
     }
 }
 
@@ -1265,7 +1296,20 @@ struct DfArgs {
     const unsigned* epoch_word;  // bumped by the back-substitution chain that follows
     unsigned* abort_word;        // == epoch: some workgroup gave up waiting
     unsigned spin_limit;         // polls before a wait gives up (set per launch from LmCtl::spin_limit_df)
+    const unsigned long long* nz;   // block structure of the factor: bit k of nz[i] = L(i, k) may be non-zero (after fill);
+                                    // null: dense.  A workgroup then only consumes the panels its row and column share,
+                                    // a structurally zero tile has no work and publishes nothing (tree orderings)
+    const unsigned char* order;     // with nz: [n_blk][64] the panels of block column j in the order they are expected to
+                                    // be finished (a column of a separator takes the panels of the subtree that is done
+                                    // first first, instead of waiting for panel 9 with panels 12-14 already there)
 };
+
+// panels k < j that block column j of the factor has an entry in (dense: all of them)
+__device__ __forceinline__ unsigned long long df_panels(const DfArgs& a, int j)
+{
+    const unsigned long long below = (1ull << j) - 1ull;   // j <= 48
+    return a.nz ? (a.nz[j] & below) : below;
+}
 
 __device__ __forceinline__ double df_value(const unsigned long long lo, const unsigned long long hi)
 {
@@ -1617,17 +1661,25 @@ template <bool HAS_T>
 __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const int lane, const int j, const int R,
                                            const Lds& m, const SliceMap& sm, const unsigned epoch, int* s_timeout, bool& ok)
 {
-    const int n_it = 8 * j;
+    const unsigned long long panels = df_panels(a, j);
+    const int n_it = 8 * __popcll(panels);
+    const unsigned char* const ord = (a.nz && a.order) ? a.order + 64 * j : nullptr;
+    unsigned long long rem = panels;   // (without an order list: ascending, the lowest set bit next)
     if (n_it > 0) {
         SliceRegs g;
         const bool sweeper = w == 0 || HAS_T;
         const int my_rb = (w == 0) ? j : R;
-        if (sweeper)
-            issue_slice(sm.at(0, my_rb, 0), lane, g);
+        // wave 1 sweeps the slices of block row R: where L(R, k) is structurally zero nobody publishes one -- zeros
+        const unsigned long long mine = (w == 0 || !a.nz || R >= a.n_blk) ? ~0ull : a.nz[R];
+        int k = ord ? (int)ord[0] : __ffsll((long long)rem) - 1;
+        if (sweeper && ((mine >> k) & 1ull))
+            issue_slice(sm.at(k, my_rb, 0), lane, g);
         for (int it = 0; it < n_it; ++it) {
-            const int k = it >> 3, r = it & 7;
+            const int r = it & 7;
+            const bool have = (mine >> k) & 1ull;
             if (sweeper) {
-                const bool got = wait_slice(sm.at(k, my_rb, r), lane, epoch, a.abort_word, k == j - 1, g, a.spin_limit);
+                const bool last_panel = it + 8 >= n_it;   // the panel expected last: swept directly instead of probed
+                const bool got = have ? wait_slice(sm.at(k, my_rb, r), lane, epoch, a.abort_word, last_panel, g, a.spin_limit) : true;
 #ifdef VMM_STAMPS
                 if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 2)
                     g_df_stamps[m.stamp_j][12 + (it - (n_it - 2))] = __builtin_amdgcn_s_memrealtime();
@@ -1636,15 +1688,19 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
                 const double nan = __longlong_as_double(0x7ff8000000000000ll);
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    X[q * kLdsRow + lane] = got ? df_value(g.lo[q], g.hi[q]) : nan;
+                    X[q * kLdsRow + lane] = !have ? 0.0 : got ? df_value(g.lo[q], g.hi[q]) : nan;
                 if (!got && lane == 0) {
                     *s_timeout = 1;
                     __hip_atomic_store(a.abort_word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             __syncthreads();
-            if (sweeper && it + 1 < n_it)   // the next slice is requested while the workers apply this one
-                issue_slice(sm.at((it + 1) >> 3, my_rb, (it + 1) & 7), lane, g);
+            if (r == 7) {   // next panel of the list
+                rem &= rem - 1ull;
+                k = (it + 1 < n_it) ? (ord ? (int)ord[(it + 1) >> 3] : __ffsll((long long)rem) - 1) : 0;
+            }
+            if (sweeper && it + 1 < n_it && ((mine >> k) & 1ull))   // the next slice is requested while the workers apply this one
+                issue_slice(sm.at(k, my_rb, (it + 1) & 7), lane, g);
         }
     }
 #ifdef VMM_STAMPS
@@ -1729,7 +1785,7 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
             }
         }
     }, Seq13{});
-    const int n_it = 8 * j;
+    const int n_it = 8 * __popcll(df_panels(a, j));
     for (int it = 0; it + 1 < n_it; ++it) {
         const double* XJ = m.Xs + (it & 1) * 2 * kDfXs;
         const double* XR = XJ + kDfXs;
@@ -1769,6 +1825,8 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     const int K0 = j * kNB;
     const int R0 = R * kNB;
     const int n_blk = a.n_blk, ld = a.ld, n_pad = a.n_pad;
+    if (HAS_T && a.nz && R < n_blk && !((a.nz[R] >> j) & 1ull))
+        return;   // L(R, j) is structurally zero: nothing to compute, nothing to publish (its consumers know)
     const unsigned epoch = *a.epoch_word + 1u;
     Lds m;
     m.RA = smem;
@@ -2055,6 +2113,8 @@ static void launch_dataflow(Engine& e, double* S, int n_pad, int ld, LmCtl* ctl,
     a.epoch_word = e.flags + 256;
     a.abort_word = e.flags + 257;
     a.spin_limit = 0;
+    a.nz = (first_blk == 0 && e.chol_nz_on) ? e.chol_nz : nullptr;
+    a.order = a.nz ? e.chol_order : nullptr;
     hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
 }
 
@@ -2068,7 +2128,8 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         // bumps the epoch both kernels tag their granules with)
         launch_dataflow(e, S, n_pad, ld, ctl, 0, n_blk);
         hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
-                           e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
+                           e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv,
+                           (const unsigned long long*)(e.chol_nz_on ? e.chol_nz : nullptr), e.flags + 261);
         return;
     }
     for (const CholLaunch& L : chol_step_schedule(n_blk, n_df)) {
@@ -2100,7 +2161,8 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
     // kernels otherwise
     if (chain) {
         hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
-                           e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
+                           e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv,
+                           (const unsigned long long*)(e.chol_nz_on ? e.chol_nz : nullptr), e.flags + 261);
     } else {
         for (int kb = n_blk - 1; kb >= 0; --kb)
             hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y,

@@ -1357,9 +1357,13 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
                 e.n_pad = n_pad_nd;
                 e.n_blk = e.n_pad / kNB;
                 e.ldz = round_up(e.n_pad + 1, kST) + 32;
-                if (getenv("VMM_BA_DEBUG"))
-                    fprintf(stderr, "[vmm_ba debug] tree ordering: %zu nodes, %d rows (%d blocks) for %d kept poses\n",
+                if (getenv("VMM_BA_DEBUG")) {
+                    fprintf(stderr, "[vmm_ba debug] tree ordering: %zu nodes, %d rows (%d blocks) for %d kept poses; node sizes:",
                             nodes.size(), e.n_pad, e.n_blk, e.n_f);
+                    for (const auto& nd : nodes)
+                        fprintf(stderr, " %zu", nd.size());
+                    fprintf(stderr, "\n");
+                }
             }
         }
     }
@@ -1528,6 +1532,70 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         if ((rc = upload(e, e.pair_tstart, tstart))) return fail(rc);
         if ((rc = upload(e, e.pair_terms, tt))) return fail(rc);
         if ((rc = upload(e, e.row_items, items))) return fail(rc);
+        if (!e.h_row_of.empty()) {
+            // Block structure of the factor under the tree ordering: the 64-row blocks a pair's 6x6 block touches, then
+            // symbolic fill (eliminating block column k couples every two block rows that have an entry in it).  From
+            // ALL observations: an observation mask only removes entries.
+            std::vector<unsigned long long> nzr((size_t)e.n_blk + 1, 0ull);
+            for (int i = 0; i < e.n_blk; ++i)
+                nzr[(size_t)i] |= 1ull << i;
+            for (int fq = 0; fq < e.n_f; ++fq)
+                for (const int32_t f2 : partners[(size_t)fq]) {
+                    const int r1 = e.h_row_of[(size_t)fq], r2 = e.h_row_of[(size_t)f2];
+                    for (int bi = r1 / kNB; bi <= (r1 + 5) / kNB; ++bi)
+                        for (int bj = r2 / kNB; bj <= (r2 + 5) / kNB; ++bj)
+                            nzr[(size_t)std::max(bi, bj)] |= 1ull << std::min(bi, bj);
+                }
+            for (int k = 0; k < e.n_blk; ++k)
+                for (int i = k + 1; i < e.n_blk; ++i)
+                    if ((nzr[(size_t)i] >> k) & 1ull)
+                        for (int j2 = k + 1; j2 <= i; ++j2)
+                            if ((nzr[(size_t)j2] >> k) & 1ull)
+                                nzr[(size_t)i] |= 1ull << j2;
+            nzr[(size_t)e.n_blk] = ~0ull;   // the right-hand side row
+            if ((rc = dev_alloc(e, &e.chol_nz, nzr.size()))) return fail(rc);
+            if ((rc = upload(e, e.chol_nz, nzr))) return fail(rc);
+            // In which order does block column j take the panels it depends on?  In the order they are expected to be
+            // finished, from a model of the kernel: a panel's slices cost ~5.6 us to apply once they are there, a
+            // block column's own factorisation ~11 us.
+            std::vector<unsigned char> ord((size_t)e.n_blk * 64, 0);
+            std::vector<double> t_done((size_t)e.n_blk, 0.0);
+            int path_max = 0;
+            std::vector<int> path((size_t)e.n_blk, 1);
+            for (int j2 = 0; j2 < e.n_blk; ++j2) {
+                std::vector<int> ks;
+                for (int k = 0; k < j2; ++k)
+                    if ((nzr[(size_t)j2] >> k) & 1ull)
+                        ks.push_back(k);
+                std::stable_sort(ks.begin(), ks.end(), [&](int x, int y) { return t_done[(size_t)x] < t_done[(size_t)y]; });
+                double t = 0.0;
+                for (size_t q = 0; q < ks.size(); ++q) {
+                    ord[(size_t)j2 * 64 + q] = (unsigned char)ks[q];
+                    t = std::max(t, t_done[(size_t)ks[q]]) + 5.6;
+                    path[(size_t)j2] = std::max(path[(size_t)j2], path[(size_t)ks[q]] + 1);
+                }
+                t_done[(size_t)j2] = t + 11.0;
+                path_max = std::max(path_max, path[(size_t)j2]);
+            }
+            if ((rc = dev_alloc(e, &e.chol_order, ord.size()))) return fail(rc);
+            if ((rc = upload(e, e.chol_order, ord))) return fail(rc);
+            if (getenv("VMM_BA_DEBUG"))
+                fprintf(stderr, "[vmm_ba debug] factor: longest chain %d of %d block columns, modelled %.0f us\n", path_max,
+                        e.n_blk, t_done[(size_t)e.n_blk - 1]);
+            e.chol_nz_on = true;
+            if (getenv("VMM_BA_DEBUG")) {
+                int nzb = 0;
+                for (int i = 0; i < e.n_blk; ++i)
+                    nzb += __builtin_popcountll(nzr[(size_t)i] & ((2ull << i) - 1ull));
+                fprintf(stderr, "[vmm_ba debug] factor structure: %d of %d lower blocks\n", nzb, e.n_blk * (e.n_blk + 1) / 2);
+                for (int i = 0; i < e.n_blk; ++i) {
+                    fprintf(stderr, "[vmm_ba debug]   %2d ", i);
+                    for (int k = 0; k <= i; ++k)
+                        fputc(((nzr[(size_t)i] >> k) & 1ull) ? 'x' : '.', stderr);
+                    fputc('\n', stderr);
+                }
+            }
+        }
         if (e.explicit_pairs) {
             std::vector<int32_t> rows((size_t)e.n_f);
             for (int fq = 0; fq < e.n_f; ++fq)
@@ -1977,9 +2045,14 @@ int vmm_ba_tag_translation_covariance(vmm_ba_handle h, int robustify, double hub
     }
     struct Restore {
         Engine& e;
-        bool v;
-        ~Restore() { e.sparse_schur = v; }
-    } restore_path{ e, was_sparse };
+        bool v, nz;
+        ~Restore()
+        {
+            e.sparse_schur = v;
+            e.chol_nz_on = nz;
+        }
+    } restore_path{ e, was_sparse, e.chol_nz_on };
+    e.chol_nz_on = false;   // the dense, naturally ordered system has no block structure to follow
     // L X = B with B = I (tags kept) or Z^T (tags eliminated), then per-tag Gram blocks
     const bool identity_rhs = e.elim_cams;
     const int n_rhs = identity_rhs ? e.n_pad : e.k_dim;
