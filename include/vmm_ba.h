@@ -170,9 +170,13 @@ typedef struct vmm_ba_summary {
     int32_t sync_timeout_kernels;   /* OR over those passes: 1 = k_chol_dataflow, 2 = k_backsolve_chain gave up,
                                        4 = another rank reported a give-up (world_size > 1) */
     int32_t block_sparse;           /* 1: the elimination ran over co-observed (camera, tag) pairs only (compressed Z,
-                                       k_schur_rows) -- what the handle chose at create from its block structure,
+                                       k_schur_pairs) -- what the handle chose at create from its block structure,
                                        VMM_BA_SCHUR=dense|sparse overrides; 0: dense Z + MFMA rank-k update */
-    int32_t reserved2;
+    int32_t tree_ordering;          /* block-sparse handles only: number of nodes of the nested-dissection tree the kept
+                                       family is ordered by (their block columns of the reduced system's factor are
+                                       computed independently of each other where the tree says so); 0: natural order.
+                                       Chosen at create when the longest chain of dependent block columns shrinks enough;
+                                       VMM_BA_ORDER=nd|natural overrides */
 } vmm_ba_summary;
 
 /* Sum-all-reduce of `count` doubles in DEVICE memory, in place, ordered on `hip_stream`

@@ -1,4 +1,4 @@
-"""Block-sparse elimination (compressed Z, k_schur_rows) against the dense path and the oracle.
+"""Block-sparse elimination (compressed Z, k_schur_pairs) against the dense path and the oracle.
 
 The reference solves with Ceres' sparse normal Cholesky under its ordering (src/TagReconstructor.cpp:725-738) and real
 projects see a handful of tags per image (README.md:155-216).  The dense path stores Z with its zero blocks and
@@ -102,3 +102,55 @@ def test_close_up_full_size_matches_oracle(oracle, monkeypatch):
     _assert_same_trace(out, summ, trace)
     _assert_same_solution(cam, tag, sc, s.tag_wh)
     np.testing.assert_array_equal(tag[0], s.tag_init[0])
+
+
+def test_tree_ordering_of_the_kept_family(oracle, monkeypatch):
+    """The close-up scene at full size: the handle orders its 200 tags by a nested dissection of the co-observation
+    graph (summary.tree_ordering = number of tree nodes), every node on a 64-row boundary of the reduced system; the
+    one-launch factorisation and the back-substitution follow the block structure of the factor.  Same LM trajectory as
+    the natural order (VMM_BA_ORDER=natural) and as the oracle; the covariance (dense, natural order inside) and a
+    forced give-up of both one-launch kernels (redone on the launch-per-column path) go through the same handle."""
+    from test_gpu_solve import _assert_same_solution, _assert_same_trace
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(2, neighbors_min=6, neighbors_max=10)
+    monkeypatch.delenv("VMM_BA_ORDER", raising=False)
+    tree, cam_t, tag_t, cov_t, again_t = _solve(s, 0, None, monkeypatch, want_cov=True)
+    assert tree["block_sparse"] == 1 and tree["tree_ordering"] >= 3 and tree["num_sync_timeouts"] == 0
+    assert again_t["iterations"] == tree["iterations"] and again_t["final_cost"] == tree["final_cost"]
+    monkeypatch.setenv("VMM_BA_ORDER", "natural")
+    nat, cam_n, tag_n, cov_n, _ = _solve(s, 0, None, monkeypatch, want_cov=True)
+    assert nat["block_sparse"] == 1 and nat["tree_ordering"] == 0
+    _assert_same_run(tree, nat, cam_t, tag_t, cam_n, tag_n, rtol=1e-9)
+    for t in range(1, len(tag_t)):
+        np.testing.assert_allclose(cov_t[t], cov_n[t], rtol=0, atol=1e-7 * np.abs(cov_n[t]).max())
+    sc = oracle.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+    summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, num_threads=8))
+    _assert_same_trace(tree, summ, trace)
+    _assert_same_solution(cam_t, tag_t, sc, s.tag_wh)
+    # every pass's factorisation gives up and is redone without inter-workgroup waits: same trajectory
+    monkeypatch.delenv("VMM_BA_ORDER", raising=False)
+    monkeypatch.setenv("VMM_BA_DEBUG_SPIN_LIMIT", "1")
+    monkeypatch.setenv("VMM_BA_DEBUG_SPIN_KERNEL", "both")
+    monkeypatch.setenv("VMM_BA_DEBUG_SPIN_ONCE", "0")
+    redo, cam_r, tag_r, _, _ = _solve(s, 0, None, monkeypatch)
+    assert redo["tree_ordering"] == tree["tree_ordering"] and redo["num_sync_timeouts"] >= 1
+    _assert_same_run(redo, tree, cam_r, tag_r, cam_t, tag_t, rtol=1e-9)
+    # a robust solve with masked observations on the tree-ordered handle against the natural order
+    monkeypatch.delenv("VMM_BA_DEBUG_SPIN_LIMIT")
+    monkeypatch.delenv("VMM_BA_DEBUG_SPIN_KERNEL")
+    monkeypatch.delenv("VMM_BA_DEBUG_SPIN_ONCE")
+    mask = np.ones(s.n_obs, np.uint8)
+    mask[::7] = 0
+    res = []
+    for order in (None, "natural"):
+        if order:
+            monkeypatch.setenv("VMM_BA_ORDER", order)
+        ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+        try:
+            ba.set_observation_mask(mask)
+            out = ba.solve(eng.default_options(robustify=1), trace_capacity=256)
+            res.append((out,) + ba.get_state())
+        finally:
+            ba.close()
+    _assert_same_run(res[0][0], res[1][0], res[0][1], res[0][2], res[1][1], res[1][2], rtol=1e-9)

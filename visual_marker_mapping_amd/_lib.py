@@ -69,7 +69,7 @@ class Summary(C.Structure):
                 ("time_eval_s", C.c_double), ("time_eliminate_s", C.c_double), ("time_factor_solve_s", C.c_double),
                 ("time_step_s", C.c_double), ("time_control_s", C.c_double),
                 ("num_sync_timeouts", C.c_int32), ("sync_timeout_kernels", C.c_int32),
-                ("block_sparse", C.c_int32), ("reserved2", C.c_int32)]
+                ("block_sparse", C.c_int32), ("tree_ordering", C.c_int32)]
 
 
 class KernelTimes(C.Structure):

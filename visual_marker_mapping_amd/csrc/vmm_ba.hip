@@ -1315,7 +1315,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     // block columns of the factor belong to one node and the block columns of two parts of one level are independent.
     {
         const char* ov = getenv("VMM_BA_ORDER");
-        if (e.sparse_schur && !e.multi && ov && !strcmp(ov, "nd") && e.n_f > 1) {
+        const bool forced = ov && !strcmp(ov, "nd"), forbidden = ov && !strcmp(ov, "natural");
+        if (e.sparse_schur && !e.multi && !forbidden && e.n_f > 1 && e.n_blk >= 4) {
             std::vector<std::vector<int32_t>> nbr((size_t)e.n_f);
             for (int q = 0; q < e.n_e; ++q)
                 for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1)
@@ -1330,7 +1331,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
             for (int fq = 0; fq < e.n_f; ++fq)
                 all[(size_t)fq] = fq;
             int32_t stamp_next = 1;
-            int leaf_max = 21;   // tags per leaf: two 64-row blocks
+            int leaf_max = 42;   // tags per leaf (four 64-row blocks; 21 and 10 measured slower on the close-up scene)
             if (const char* lv = getenv("VMM_BA_ND_LEAF"))
                 leaf_max = std::max(1, atoi(lv));
             std::vector<std::vector<int32_t>> nodes;
@@ -1345,7 +1346,40 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
                 }
             }
             const int n_pad_nd = round_up(row, kNB);
-            if (nodes.size() > 2 && dataflow_workgroups(n_pad_nd / kNB) <= dataflow_max_workgroups(e.n_cu)) {
+            // Worth it?  The factorisation is a chain of dependent block columns (~11 us each): the longest chain under
+            // the tree ordering (block structure after symbolic fill, nodes as dense blocks: an upper bound) against the
+            // n_blk of the natural order.  Taken when it is at most 0.7 of it (VMM_BA_ORDER=nd: always).
+            bool take = nodes.size() > 2 && dataflow_workgroups(n_pad_nd / kNB) <= dataflow_max_workgroups(e.n_cu);
+            if (take && !forced) {
+                const int nb = n_pad_nd / kNB;
+                std::vector<unsigned long long> nzr((size_t)nb, 0ull);
+                for (int i = 0; i < nb; ++i)
+                    nzr[(size_t)i] = 1ull << i;
+                for (int fq = 0; fq < e.n_f; ++fq)
+                    for (const int32_t f2 : nbr[(size_t)fq]) {
+                        const int r1 = rows[(size_t)fq], r2 = rows[(size_t)f2];
+                        for (int bi = r1 / kNB; bi <= (r1 + 5) / kNB; ++bi)
+                            for (int bj = r2 / kNB; bj <= (r2 + 5) / kNB; ++bj)
+                                nzr[(size_t)std::max(bi, bj)] |= 1ull << std::min(bi, bj);
+                    }
+                std::vector<int> path((size_t)nb, 1);
+                int path_max = 1;
+                for (int k = 0; k < nb; ++k) {
+                    for (int i = k + 1; i < nb; ++i)
+                        if ((nzr[(size_t)i] >> k) & 1ull) {
+                            for (int j2 = k + 1; j2 <= i; ++j2)
+                                if ((nzr[(size_t)j2] >> k) & 1ull)
+                                    nzr[(size_t)i] |= 1ull << j2;
+                            path[(size_t)i] = std::max(path[(size_t)i], path[(size_t)k] + 1);
+                        }
+                    path_max = std::max(path_max, path[(size_t)k]);
+                }
+                take = path_max * 10 <= e.n_blk * 7;
+                if (getenv("VMM_BA_DEBUG"))
+                    fprintf(stderr, "[vmm_ba debug] tree ordering candidate: longest chain %d of %d block columns against %d in "
+                                    "natural order -> %s\n", path_max, nb, e.n_blk, take ? "taken" : "not taken");
+            }
+            if (take) {
                 e.h_row_of = rows;
                 e.nd_node_first_blk.clear();
                 int r2 = 0;
@@ -1906,6 +1940,7 @@ int vmm_ba_solve(vmm_ba_handle h, const vmm_ba_options* opt, vmm_ba_summary* s)
     s->num_sync_timeouts = c.num_sync_timeouts;
     s->sync_timeout_kernels = c.sync_kernels;
     s->block_sparse = e.sparse_schur ? 1 : 0;
+    s->tree_ordering = (e.sparse_schur && !e.h_row_of.empty()) ? (int32_t)e.nd_node_first_blk.size() : 0;
     if (user_trace && user_cap > 0) {
         const int n = std::min(c.records, user_cap);
         if (n > 0) {

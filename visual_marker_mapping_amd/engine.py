@@ -136,7 +136,7 @@ class BundleAdjuster:
             s.trace, s.trace_capacity = buf, trace_capacity
         _lib.check(_lib.lib().vmm_ba_solve(self._h, C.byref(o), C.byref(s)))
         out = {k: getattr(s, k) for k, _ in _lib.Summary._fields_
-               if k not in ("trace", "trace_capacity", "reserved", "reserved2")}
+               if k not in ("trace", "trace_capacity", "reserved")}
         trace = []
         if buf is not None:
             for i in range(min(s.iterations, trace_capacity)):
