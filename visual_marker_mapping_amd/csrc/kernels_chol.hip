@@ -941,9 +941,16 @@ int backsolve_chain_workgroups(int n_blk) { return n_blk; }
 
 // The workgroup that finishes LAST retires the epoch (every workgroup has read the old value at its start by then; with
 // a tree ordering block 0 is not the last to finish any more) and leaves the counter at zero for the next launch.
-__device__ __forceinline__ void chain_block_done(unsigned* n_done, int n_blk, unsigned* epoch_word, unsigned epoch)
+// (dense chains end with block 0 by construction: it retires the epoch with a plain store, as before -- the returning
+// atomic costs the last workgroup, i.e. the launch, ~1-2 us)
+__device__ __forceinline__ void chain_block_done(unsigned* n_done, int n_blk, unsigned* epoch_word, unsigned epoch,
+                                                 bool tree, int m)
 {
-    __threadfence();
+    if (!tree) {
+        if (m == 0)
+            *epoch_word = epoch;
+        return;
+    }
     if (atomicAdd(n_done, 1u) == (unsigned)n_blk - 1u) {
         *n_done = 0u;
         *epoch_word = epoch;
@@ -969,6 +976,201 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
                                                          int n_pad, int n_blk, double* y,
                                                          const double* __restrict__ dinv, unsigned long long* gran,
                                                          unsigned* epoch_word, const double* __restrict__ Ld,
+                                                         const double* __restrict__ Linv)
+{
+    // (a give-up inside the dataflow factorisation before this launch has set done = 2: a workgroup that stops
+    // waiting poisons and still publishes, so the factorisation's last workgroup ends after every give-up and sees
+    // the abort word)
+    if (ctl->done || ctl->lin_fail) {
+        // the factorisation before this launch may have tagged granules with the current epoch: retire it even
+        // when the solve is skipped (every workgroup of this launch leaves here, so nobody needs the old value)
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+            *epoch_word = *epoch_word + 1u;
+        return;
+    }
+    const unsigned spin_limit = ctl->spin_limit_chain ? ctl->spin_limit_chain : kSpinLimit;
+    __shared__ double L[64 * kLd];    // L(m+1, m) for the product B_m
+    __shared__ double Li[64 * kLd];   // Linv_m
+    __shared__ double red[4][64];
+    __shared__ double ws[64];
+    __shared__ double ys[2][64];
+    __shared__ double sB[16][256];    // B_m: [row within a wave's 16][thread that owns the column]
+    __shared__ int s_timeout;
+    const int m = n_blk - 1 - (int)blockIdx.x;
+    const int tid = threadIdx.x;
+    const int c = tid & 63, part = tid >> 6;
+    const unsigned epoch = *epoch_word + 1u;   // every workgroup reads it before workgroup n_blk-1 (the last) bumps it
+    const int K0 = m * kNB;
+    if (tid == 0)
+        s_timeout = 0;
+    CH_RT(m, 0);
+    // wave 0 sweeps block j's granules into ysj: lane c owns unknown c (two granules)
+    auto receive = [&](const int j, double* ysj) {
+        if (part == 0) {
+            const unsigned long long* g = gran + 2 * (int64_t)(j * kNB + c);
+            unsigned long long x0, x1;
+            for (unsigned n = 0;;) {
+                x0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
+                if (__all(ok) && spin_limit != 1u)   // a limit of 1 (debugging) gives up even on valid data
+                    break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++n >= spin_limit) {   // wave-uniform give-up: reported as a synchronisation time-out below
+                    s_timeout = 1;
+                    break;
+                }
+            }
+            ysj[c] = __longlong_as_double((long long)(((x1 & 0xffffffffull) << 32) | (x0 & 0xffffffffull)));
+        }
+    };
+    auto publish = [&](const double yv) {   // wave 0
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(yv);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        unsigned long long* g = gran + 2 * (int64_t)(K0 + c);
+        __hip_atomic_store(g, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[K0 + c] = yv;   // for the kernels after this launch
+    };
+    if (m == n_blk - 1) {
+        // The last block is the first in the chain and has no inverse (nothing runs beside its factorisation).  ONE
+        // wave solves L^T y = w by columns, lane c holding w[c]: 64 steps of (broadcast y_j from lane j, one
+        // multiply-add per lane) on registers only -- no barrier, no LDS in the dependent chain.
+        if (part == 0) {
+            double lcol[64];
+#pragma unroll
+            for (int jj = 0; jj < 64; ++jj)
+                lcol[jj] = (c <= jj) ? Ld[(int64_t)m * 4096 + jj * 64 + c] : 0.0;
+            const double dic = dinv[K0 + c];
+            double wv = S[(int64_t)n_pad * ld + K0 + c];
+            double yv = 0.0;
+#pragma unroll
+            for (int jj = 63; jj >= 0; --jj) {
+                // v_readlane (jj is a constant), not a cross-lane permute through the LDS
+                const long long wb = __double_as_longlong(wv * dic);
+                const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)wb, jj);
+                const unsigned w1 = (unsigned)__builtin_amdgcn_readlane((int)(wb >> 32), jj);
+                const double yj = __longlong_as_double((long long)(((unsigned long long)w1 << 32) | w0));
+                yv = (c == jj) ? yj : yv;
+                wv = (c < jj) ? wv - lcol[jj] * yj : wv;
+            }
+            publish(yv);
+        }
+        CH_RT(m, 2);
+        if (tid == 0 && m == 0)
+            *epoch_word = epoch;   // a single block: also the end of the chain
+        return;   // no wait, so no timeout
+    }
+    // ---- B_m = L(m+1, m) Linv_m on the matrix cores: wave `part` computes rows part*16 .. part*16+15 ----
+    // (as 16 x 64 dot products per thread with broadcast LDS reads it took 15 us: every workgroup was late for its hop)
+    double li[16];
+    {
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int r = idx >> 6, cc = idx & 63;
+            L[r * kLd + cc] = S[(int64_t)((m + 1) * kNB + r) * ld + K0 + cc];
+            Li[r * kLd + cc] = Linv[(int64_t)m * 4096 + r * 64 + cc];   // lower triangular, zero above the diagonal
+        }
+        __syncthreads();
+        // li: my 16 rows of column c of Linv_m, for u_m = Linv_m^T t
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            li[r] = Li[(part * 16 + r) * kLd + c];
+        // v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+        // C[row = (lane >> 4) + 4 reg][col = lane & 15]
+        const int fi = c & 15, fk = c >> 4;
+        double4_t accB[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            accB[t] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double av = L[(part * 16 + fi) * kLd + 4 * ks + fk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                accB[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Li[(4 * ks + fk) * kLd + 16 * t + fi], accB[t], 0, 0, 0);
+        }
+        // to the layout the hop reads: sB[row within my 16][workgroup thread that owns the column]
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sB[fk + 4 * r][part * 64 + 16 * t + fi] = accB[t][r];
+        __syncthreads();
+    }
+    // ---- the blocks behind m+1: acc = sum_j L(j, m)^T y_j ----
+    double acc = 0.0;
+    double lt[16], ln[16];
+    int j = n_blk - 1;
+    if (j > m + 1) {
+        const double* Lb = S + (int64_t)(j * kNB + part * 16) * ld + K0 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            lt[r] = Lb[(int64_t)r * ld];
+    }
+    for (; j > m + 1; --j) {
+        if (j - 1 > m + 1) {   // next tile requested before the wait
+            const double* Lb = S + (int64_t)((j - 1) * kNB + part * 16) * ld + K0 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ln[r] = Lb[(int64_t)r * ld];
+        }
+        double* ysj = ys[j & 1];
+        receive(j, ysj);
+        __syncthreads();   // also orders the reuse of ys[j & 1] two hops later
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc += lt[r] * ysj[part * 16 + r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            lt[r] = ln[r];
+    }
+    // ---- u_m = Linv_m^T (w_m - acc): one hop ahead of the value it will be combined with ----
+    red[part][c] = acc;
+    __syncthreads();
+    if (part == 0)
+        ws[c] = S[(int64_t)n_pad * ld + K0 + c] - ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    __syncthreads();
+    double a2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        a2 += li[r] * ws[part * 16 + r];
+    __syncthreads();   // everyone has read red[] above
+    red[part][c] = a2;
+    __syncthreads();
+    double u = 0.0;
+    if (part == 0)
+        u = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    // ---- the hop: y_m = u_m - B_m^T y_{m+1} ----
+    double* ysj = ys[(m + 1) & 1];
+    receive(m + 1, ysj);
+    __syncthreads();   // also: everyone has read red[] above
+    CH_RT(m, 1);
+    double a3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        a3 += sB[r][tid] * ysj[part * 16 + r];
+    red[part][c] = a3;
+    __syncthreads();
+    if (part == 0)
+        publish(u - ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])));
+    CH_RT(m, 2);
+    if (tid == 0) {
+        if (s_timeout)
+            raise_sync_timeout(ctl, 2);
+        if (m == 0)
+            *epoch_word = epoch;   // block 0 is the end of the chain: every other workgroup has read the old value
+    }
+}
+
+// The same chain for a factor with a block structure (tree orderings of the kept family, `nz` as in DfArgs): block m waits
+// only for the blocks j > m with L(j, m) != 0, its hop is on the nearest of them (the parent in the elimination tree)
+// instead of m + 1, and the workgroup that finishes LAST retires the epoch (block 0 is no longer the last).  A kernel of
+// its own: the dense chain above stays exactly the code that was tuned (measured A/B on one box: the merged form cost
+// the dense chain ~2 us).
+__global__ __launch_bounds__(256) void k_backsolve_chain_tree(LmCtl* ctl, const double* __restrict__ S, int ld,
+                                                         int n_pad, int n_blk, double* y,
+                                                         const double* __restrict__ dinv, unsigned long long* gran,
+                                                         unsigned* epoch_word, const double* __restrict__ Ld,
                                                          const double* __restrict__ Linv,
                                                          const unsigned long long* __restrict__ nz, unsigned* n_done)
 {
@@ -979,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
         // the factorisation before this launch may have tagged granules with the current epoch: retire it even
         // when the solve is skipped (every workgroup of this launch leaves here, so nobody needs the old value)
         if (threadIdx.x == 0)
-            chain_block_done(n_done, n_blk, epoch_word, *epoch_word + 1u);
+            chain_block_done(n_done, n_blk, epoch_word, *epoch_word + 1u, nz != nullptr, n_blk - 1 - (int)blockIdx.x);
         return;
     }
     const unsigned spin_limit = ctl->spin_limit_chain ? ctl->spin_limit_chain : kSpinLimit;
@@ -1052,7 +1254,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
         }
         CH_RT(m, 2);
         if (tid == 0)
-            chain_block_done(n_done, n_blk, epoch_word, epoch);
+            chain_block_done(n_done, n_blk, epoch_word, epoch, nz != nullptr, m);
         return;   // no wait, so no timeout
     }
     // The blocks of column m below the diagonal.  Dense: all of m+1 .. n_blk-1, and the hop waits for y_{m+1}.  With the
@@ -1171,7 +1373,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
     if (tid == 0) {
         if (s_timeout)
             raise_sync_timeout(ctl, 2);
-        chain_block_done(n_done, n_blk, epoch_word, epoch);
+        chain_block_done(n_done, n_blk, epoch_word, epoch, nz != nullptr, m);
     }
 }
 
@@ -1657,28 +1859,31 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
     }
 }
 
-template <bool HAS_T>
+// TREE: the factor has a block structure (DfArgs::nz, tree orderings): only the panels this block column depends on are
+// consumed, in DfArgs::order.  !TREE is the dense kernel: panels 0 .. j-1 in ascending order.
+template <bool HAS_T, bool TREE>
 __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const int lane, const int j, const int R,
                                            const Lds& m, const SliceMap& sm, const unsigned epoch, int* s_timeout, bool& ok)
 {
-    const unsigned long long panels = df_panels(a, j);
-    const int n_it = 8 * __popcll(panels);
-    const unsigned char* const ord = (a.nz && a.order) ? a.order + 64 * j : nullptr;
-    unsigned long long rem = panels;   // (without an order list: ascending, the lowest set bit next)
+    const int n_it = TREE ? 8 * __popcll(df_panels(a, j)) : 8 * j;
     if (n_it > 0) {
         SliceRegs g;
         const bool sweeper = w == 0 || HAS_T;
         const int my_rb = (w == 0) ? j : R;
-        // wave 1 sweeps the slices of block row R: where L(R, k) is structurally zero nobody publishes one -- zeros
-        const unsigned long long mine = (w == 0 || !a.nz || R >= a.n_blk) ? ~0ull : a.nz[R];
-        int k = ord ? (int)ord[0] : __ffsll((long long)rem) - 1;
+        const unsigned char* const ord = TREE ? a.order + 64 * j : nullptr;
+        // TREE: wave 1 sweeps the slices of block row R; where L(R, k) is structurally zero nobody publishes one -- zeros
+        const unsigned long long mine = (!TREE || w == 0 || R >= a.n_blk) ? ~0ull : a.nz[R];
+        int k = TREE ? (int)ord[0] : 0;
         if (sweeper && ((mine >> k) & 1ull))
             issue_slice(sm.at(k, my_rb, 0), lane, g);
         for (int it = 0; it < n_it; ++it) {
             const int r = it & 7;
-            const bool have = (mine >> k) & 1ull;
+            if (!TREE)
+                k = it >> 3;
+            const bool have = !TREE || ((mine >> k) & 1ull);
             if (sweeper) {
-                const bool last_panel = it + 8 >= n_it;   // the panel expected last: swept directly instead of probed
+                // the panel expected last (dense: the one right before mine) is swept directly instead of probed
+                const bool last_panel = TREE ? it + 8 >= n_it : k == j - 1;
                 const bool got = have ? wait_slice(sm.at(k, my_rb, r), lane, epoch, a.abort_word, last_panel, g, a.spin_limit) : true;
 #ifdef VMM_STAMPS
                 if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 2)
@@ -1687,20 +1892,24 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
                 double* X = m.Xs + (it & 1) * 2 * kDfXs + (w == 0 ? 0 : kDfXs);
                 const double nan = __longlong_as_double(0x7ff8000000000000ll);
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    X[q * kLdsRow + lane] = !have ? 0.0 : got ? df_value(g.lo[q], g.hi[q]) : nan;
+                for (int q = 0; q < 8; ++q) {
+                    const double v = got ? df_value(g.lo[q], g.hi[q]) : nan;
+                    X[q * kLdsRow + lane] = (TREE && !have) ? 0.0 : v;
+                }
                 if (!got && lane == 0) {
                     *s_timeout = 1;
                     __hip_atomic_store(a.abort_word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             __syncthreads();
-            if (r == 7) {   // next panel of the list
-                rem &= rem - 1ull;
-                k = (it + 1 < n_it) ? (ord ? (int)ord[(it + 1) >> 3] : __ffsll((long long)rem) - 1) : 0;
+            if (TREE) {
+                if (r == 7 && it + 1 < n_it)   // next panel of the list
+                    k = (int)ord[(it + 1) >> 3];
+                if (sweeper && it + 1 < n_it && ((mine >> k) & 1ull))
+                    issue_slice(sm.at(k, my_rb, (it + 1) & 7), lane, g);
+            } else if (sweeper && it + 1 < n_it) {   // the next slice is requested while the workers apply this one
+                issue_slice(sm.at((it + 1) >> 3, my_rb, (it + 1) & 7), lane, g);
             }
-            if (sweeper && it + 1 < n_it && ((mine >> k) & 1ull))   // the next slice is requested while the workers apply this one
-                issue_slice(sm.at(k, my_rb, (it + 1) & 7), lane, g);
         }
     }
 #ifdef VMM_STAMPS
@@ -1758,7 +1967,7 @@ __device__ __forceinline__ void worker_round(const int lane, double4_t (&acc)[13
     if (J0 == 16) DF_CY(54);
 }
 
-template <int WK, bool HAS_T>
+template <int WK, bool HAS_T, bool TREE>
 __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, const int j, const int R, const Lds& m)
 {
     const int fr = lane & 15, fk = lane >> 4;
@@ -1785,7 +1994,7 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
             }
         }
     }, Seq13{});
-    const int n_it = 8 * __popcll(df_panels(a, j));
+    const int n_it = TREE ? 8 * __popcll(df_panels(a, j)) : 8 * j;
     for (int it = 0; it + 1 < n_it; ++it) {
         const double* XJ = m.Xs + (it & 1) * 2 * kDfXs;
         const double* XR = XJ + kDfXs;
@@ -1816,7 +2025,7 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
     worker_round<WK, 56, HAS_T>(lane, acc, m);
 }
 
-template <bool HAS_T>
+template <bool HAS_T, bool TREE>
 __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, double* smem)
 {
     const int tid = threadIdx.x;
@@ -1825,7 +2034,7 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     const int K0 = j * kNB;
     const int R0 = R * kNB;
     const int n_blk = a.n_blk, ld = a.ld, n_pad = a.n_pad;
-    if (HAS_T && a.nz && R < n_blk && !((a.nz[R] >> j) & 1ull))
+    if (TREE && HAS_T && R < n_blk && !((a.nz[R] >> j) & 1ull))
         return;   // L(R, j) is structurally zero: nothing to compute, nothing to publish (its consumers know)
     const unsigned epoch = *a.epoch_word + 1u;
     Lds m;
@@ -1855,11 +2064,11 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     __syncthreads();   // s_timeout
     bool ok = true;
     if (w < 2)
-        pivot_path<HAS_T>(a, w, lane, j, R, m, sm, epoch, &s_timeout, ok);
+        pivot_path<HAS_T, TREE>(a, w, lane, j, R, m, sm, epoch, &s_timeout, ok);
     else if (w == 2)
-        worker_path<0, HAS_T>(a, lane, j, R, m);
+        worker_path<0, HAS_T, TREE>(a, lane, j, R, m);
     else
-        worker_path<1, HAS_T>(a, lane, j, R, m);
+        worker_path<1, HAS_T, TREE>(a, lane, j, R, m);
     __syncthreads();   // the pivot waves store their rows of the result tile behind the last round's barrier
     // results for the kernels after this launch
     if (!HAS_T) {
@@ -1900,7 +2109,8 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
 
 } // namespace df2
 
-__global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
+template <bool TREE>
+__device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
 {
     if (a.ctl->done)
         return;
@@ -1919,9 +2129,20 @@ __global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
     if (j >= a.n_blk)
         return;
     if (b < a.n_blk - j)
-        df2::role<true>(a, j, j + 1 + b, smem);
+        df2::role<true, TREE>(a, j, j + 1 + b, smem);
     else
-        df2::role<false>(a, j, j, smem);
+        df2::role<false, TREE>(a, j, j, smem);
+}
+
+__global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
+{
+    chol_dataflow_body<false>(a);
+}
+
+// the same launch for a factor with a block structure (DfArgs::nz / order: tree orderings of the kept family)
+__global__ __launch_bounds__(256) void k_chol_dataflow_tree(DfArgs a)
+{
+    chol_dataflow_body<true>(a);
 }
 
 // One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their own column
@@ -2115,7 +2336,22 @@ static void launch_dataflow(Engine& e, double* S, int n_pad, int ld, LmCtl* ctl,
     a.spin_limit = 0;
     a.nz = (first_blk == 0 && e.chol_nz_on) ? e.chol_nz : nullptr;
     a.order = a.nz ? e.chol_order : nullptr;
-    hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
+    if (a.nz)
+        hipLaunchKernelGGL(k_chol_dataflow_tree, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
+    else
+        hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
+}
+
+static void launch_backsolve_chain(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl)
+{
+    const int n_blk = n_pad / kNB;
+    if (e.chol_nz_on)
+        hipLaunchKernelGGL(k_backsolve_chain_tree, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld,
+                           n_pad, n_blk, y, e.dinv, e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv,
+                           (const unsigned long long*)e.chol_nz, e.flags + 261);
+    else
+        hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld,
+                           n_pad, n_blk, y, e.dinv, e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv);
 }
 
 void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, LmCtl* ctl, bool safe)
@@ -2127,9 +2363,7 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
         // one launch for the factorisation + forward substitution, one for the back-substitution chain (which
         // bumps the epoch both kernels tag their granules with)
         launch_dataflow(e, S, n_pad, ld, ctl, 0, n_blk);
-        hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
-                           e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv,
-                           (const unsigned long long*)(e.chol_nz_on ? e.chol_nz : nullptr), e.flags + 261);
+        launch_backsolve_chain(e, S, n_pad, ld, y, ctl);
         return;
     }
     for (const CholLaunch& L : chol_step_schedule(n_blk, n_df)) {
@@ -2160,9 +2394,7 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
     // one chained launch while every workgroup of the chain is certainly resident (one per CU); the per-block
     // kernels otherwise
     if (chain) {
-        hipLaunchKernelGGL(k_backsolve_chain, dim3(backsolve_chain_workgroups(n_blk)), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, y, e.dinv,
-                           e.gran, e.flags + 256, (const double*)e.Ldiag, (const double*)e.Linv,
-                           (const unsigned long long*)(e.chol_nz_on ? e.chol_nz : nullptr), e.flags + 261);
+        launch_backsolve_chain(e, S, n_pad, ld, y, ctl);
     } else {
         for (int kb = n_blk - 1; kb >= 0; --kb)
             hipLaunchKernelGGL(k_backsolve_step, dim3(kb + 1), dim3(256), 0, e.stream, ctl, S, ld, n_pad, n_blk, kb, y,
@@ -2178,7 +2410,9 @@ int preload_chol_kernels()
     int bad = 0;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsolve_step)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsolve_chain)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsolve_chain_tree)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow_tree)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_step)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_inverse)) != hipSuccess;
     return bad;
