@@ -154,3 +154,33 @@ def test_tree_ordering_of_the_kept_family(oracle, monkeypatch):
         finally:
             ba.close()
     _assert_same_run(res[0][0], res[1][0], res[0][1], res[0][2], res[1][1], res[1][2], rtol=1e-9)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_tree_ordering_random_close_up_scenes(monkeypatch, seed):
+    """Walls of 70 to 380 tags seen 3..14 at a time (some tags unseen, the graph in several pieces now and then), both
+    eliminations: forced tree ordering against the natural order -- the same LM trajectory."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    rng = np.random.default_rng(100 + seed)
+    n_tags = int(rng.integers(70, 380))
+    n_cams = int(rng.integers(n_tags // 2, 2 * n_tags))
+    lo = int(rng.integers(3, 8))
+    s = make_scene(5 if seed % 2 else 1, n_cams=n_cams, n_tags=n_tags, neighbors_min=lo, neighbors_max=lo + int(rng.integers(0, 7)))
+    robust = seed % 2
+    elim = eng.ELIM_CAMERAS if seed % 3 else eng.ELIM_TAGS
+    runs = []
+    for order in ("nd", "natural"):
+        monkeypatch.setenv("VMM_BA_ORDER", order)
+        monkeypatch.setenv("VMM_BA_SCHUR", "sparse")
+        ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px,
+                                elimination=elim)
+        try:
+            out = ba.solve(eng.default_options(robustify=robust, max_num_iterations=12), trace_capacity=64)
+            runs.append((out,) + ba.get_state())
+        finally:
+            ba.close()
+    assert runs[1][0]["tree_ordering"] == 0 and runs[0][0]["num_sync_timeouts"] == 0
+    _assert_same_run(runs[0][0], runs[1][0], runs[0][1], runs[0][2], runs[1][1], runs[1][2], rtol=1e-8)
+    print("seed %d: %d cams x %d tags, elimination %s, tree nodes %d" % (seed, n_cams, n_tags, "cams" if elim == eng.ELIM_CAMERAS else "tags",
+                                                                         runs[0][0]["tree_ordering"]))
