@@ -223,6 +223,9 @@ def main():
                                       "Huber(1.0)" if robust else "no loss"),
                        "eliminated_family": "cameras" if elim_cams else "tags",
                        "reduced_system_order": 6 * (n_tags if elim_cams else n_cams),
+                       "elimination_form": "block-sparse (k_schur_pairs)" if last.get("block_sparse") else "dense Z + MFMA rank-k",
+                       "kept_family_order": ("nested-dissection tree, %d nodes" % last["tree_ordering"]) if last.get("tree_ordering")
+                                            else "natural",
                        "solves_timed": solves, "lm_iterations_per_solve": last["num_lm_iterations"],
                        "sharding": "observations by %s" % ("camera" if elim_cams else "tag")},
             "residual_evals_per_sec": res_evals_per_s,
@@ -280,9 +283,13 @@ def main():
         dataflow = n_blk <= 48          # dataflow_max_workgroups (csrc/kernels_chol.hip)
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
-        names = {"cholesky_solve": ("k_chol_dataflow (one launch: %d workgroups, %d block columns) + k_backsolve_chain"
+        tree = int(last.get("tree_ordering", 0)) if isinstance(last, dict) else 0
+        names = {"cholesky_solve": ("k_chol_dataflow_tree + k_backsolve_chain_tree (kept family ordered by a nested-dissection "
+                                    "tree of %d nodes; natural order: %d block columns)" % (tree, n_blk)) if tree else
+                                   ("k_chol_dataflow (one launch: %d workgroups, %d block columns) + k_backsolve_chain"
                                     % (n_blk * (n_blk + 1) // 2 + n_blk, n_blk)) if dataflow else
-                                   ("cholesky_solve = %d x k_chol_step + k_backsolve_chain" % n_blk),
+                                   ("cholesky_solve = %d x k_chol_step + k_chol_dataflow on the last block columns + "
+                                    "k_backsolve_chain" % max(n_blk - 34, 0)),
                  "schur_syrk": "k_syrk_streamk", "eval_jacobian": "k_eval_both + k_reduce_pose", "eval_cost": "k_cost"}
         line["roofline"] = {"kernel": names.get(dom, dom), "bound": d["bound"], "achieved": d["achieved"],
                             "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": traffic.get(dom),
