@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--visibility", type=float, default=1.0)
     ap.add_argument("--neighbors", type=int, nargs=2, default=None, metavar=("MIN", "MAX"),
                     help="close-up scene: every image sees the MIN..MAX tags nearest to the wall point it looks at")
+    ap.add_argument("--wall-rows", type=int, default=0,
+                    help="with --neighbors: the tags hang in this many rows (1 or 2: a corridor) instead of a wall")
     ap.add_argument("--poll", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", choices=["rccl", "callback"], default="rccl",
@@ -146,6 +148,8 @@ def main():
         overrides["visibility"] = a.visibility
     if a.neighbors:
         overrides["neighbors_min"], overrides["neighbors_max"] = a.neighbors
+    if a.wall_rows > 0:
+        overrides["wall_rows"] = a.wall_rows
     s = make_scene(a.config, **overrides)
     n_cams, n_tags = len(s.cam_init), len(s.tag_init)
     elim = {"auto": eng.ELIM_AUTO, "cams": eng.ELIM_CAMERAS, "tags": eng.ELIM_TAGS}[a.elimination]

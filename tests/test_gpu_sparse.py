@@ -158,7 +158,7 @@ def test_tree_ordering_of_the_kept_family(oracle, monkeypatch):
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_tree_ordering_random_close_up_scenes(monkeypatch, seed):
-    """Walls of 70 to 380 tags seen 3..14 at a time (some tags unseen, the graph in several pieces now and then), both
+    """Walls and corridors (tags in 1, 2 or 4 rows) of 70 to 380 tags seen 3..14 at a time (some tags unseen, the graph in several pieces now and then), both
     eliminations: forced tree ordering against the natural order -- the same LM trajectory."""
     from visual_marker_mapping_amd import engine as eng
     from visual_marker_mapping_amd.synthetic import make_scene
@@ -166,7 +166,8 @@ def test_tree_ordering_random_close_up_scenes(monkeypatch, seed):
     n_tags = int(rng.integers(70, 380))
     n_cams = int(rng.integers(n_tags // 2, 2 * n_tags))
     lo = int(rng.integers(3, 8))
-    s = make_scene(5 if seed % 2 else 1, n_cams=n_cams, n_tags=n_tags, neighbors_min=lo, neighbors_max=lo + int(rng.integers(0, 7)))
+    s = make_scene(5 if seed % 2 else 1, n_cams=n_cams, n_tags=n_tags, neighbors_min=lo, neighbors_max=lo + int(rng.integers(0, 7)),
+                   wall_rows=(0, 1, 2, 0, 4, 0)[seed])   # walls and corridors
     robust = seed % 2
     elim = eng.ELIM_CAMERAS if seed % 3 else eng.ELIM_TAGS
     runs = []

@@ -35,6 +35,8 @@ typedef struct vmm_scene_cfg {
      * stands in front of a random point of the wall and sees the neighbors_min..neighbors_max tags nearest to it
      * (`visibility` is ignored).  The reduced systems of such scenes are block-sparse. */
     int neighbors_min, neighbors_max;
+    /* > 0: the tags hang in this many rows (a corridor: 1 or 2) instead of a wall about twice as wide as high */
+    int wall_rows;
 } vmm_scene_cfg;
 
 typedef struct rng {
@@ -180,7 +182,7 @@ int vmm_scene_generate(const vmm_scene_cfg* cfg, double intr[4], double dist[5],
         dist[2] = -2.9390604003594177e-04; dist[3] = 4.1533180829908799e-04;
         dist[4] = 5.7043887874185996e-02;
     }
-    const int gw = (int)ceil(sqrt(2.0 * nt));
+    const int gw = cfg->wall_rows > 0 ? (nt + cfg->wall_rows - 1) / cfg->wall_rows : (int)ceil(sqrt(2.0 * nt));
     const int gh = (nt + gw - 1) / gw;
     const double pitch = 0.30, side = 0.1285; /* main_detection.cpp:43,48 default marker size */
     for (int t = 0; t < nt; ++t) {

@@ -20,7 +20,7 @@ class SceneCfg(C.Structure):
                 ("visibility", C.c_double), ("noise_px", C.c_double), ("outlier_frac", C.c_double),
                 ("outlier_px", C.c_double), ("use_distortion", C.c_int), ("cam_rot_deg", C.c_double),
                 ("cam_trans_m", C.c_double), ("tag_rot_deg", C.c_double), ("tag_trans_m", C.c_double),
-                ("neighbors_min", C.c_int), ("neighbors_max", C.c_int)]
+                ("neighbors_min", C.c_int), ("neighbors_max", C.c_int), ("wall_rows", C.c_int)]
 
 
 def build(force=False):
