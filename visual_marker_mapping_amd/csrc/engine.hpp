@@ -185,6 +185,7 @@ struct Engine {
     int32_t* pair_terms = nullptr;  // [n_terms][2] position of the left block in the row's observation list | E-order
                                     // index of the right block (rhs pair: the eliminated pose)
     int32_t* row_items = nullptr;   // [2][n_row_items]
+    double co_terms = 0.0;          // sum over the eliminated poses of (observations)^2: size of the host's pair bookkeeping
     bool explicit_pairs = false;    // only the pairs that share an eliminated pose are listed (pair_col), S zero-filled first
     int32_t* pair_col = nullptr;    // [n_pairs] first column of the pair's block in S (-1: the row's right-hand side entry)
     int32_t* row_of = nullptr;      // [n_f] first row of every kept pose in the reduced system (explicit form only)

@@ -1294,9 +1294,11 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     // VMM_BA_SCHUR=dense|sparse overrides.
     {
         double pairs = 0.0;   // 6x6 block products of the lower triangle: sum over e of deg (deg + 1) / 2
+        e.co_terms = 0.0;
         for (int q = 0; q < e.n_e; ++q) {
             const double deg = (double)(startE[q + 1] - startE[q]);
             pairs += 0.5 * deg * (deg + 1.0);
+            e.co_terms += deg * deg;   // entries the host's adjacency lists of the kept family would hold before merging
         }
         const double dense_flops = (double)(e.n_pad + 1) * (e.n_pad + 2) * e.k_dim;
         const double sparse_flops = 432.0 * pairs + 72.0 * (double)e.n_obs;
@@ -1316,7 +1318,9 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     {
         const char* ov = getenv("VMM_BA_ORDER");
         const bool forced = ov && !strcmp(ov, "nd"), forbidden = ov && !strcmp(ov, "natural");
-        if (e.sparse_schur && !e.multi && !forbidden && e.n_f > 1 && e.n_blk >= 4) {
+        // (the host-side graph work is bounded: 5e7 list entries, and a natural order beyond the one-launch kernel's 48 block
+        // columns cannot become a tree order within them)
+        if (e.sparse_schur && !e.multi && !forbidden && e.n_f > 1 && e.n_blk >= 4 && e.n_blk <= 48 && e.co_terms <= 5e7) {
             std::vector<std::vector<int32_t>> nbr((size_t)e.n_f);
             for (int q = 0; q < e.n_e; ++q)
                 for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1)
@@ -1448,7 +1452,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
             double co = 0.0;   // co-observed pairs incl. the diagonal, counted once
             std::vector<int32_t> mark((size_t)e.n_f, -1);
             std::vector<std::vector<int32_t>> adj((size_t)e.n_f);
-            for (int q = 0; q < e.n_e; ++q)
+            const bool list_pairs = !e.h_row_of.empty() || e.co_terms <= 5e7;   // else: the implicit form
+            for (int q = 0; q < e.n_e && list_pairs; ++q)
                 for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1)
                     for (int32_t d2 = startE[q]; d2 < startE[q + 1]; ++d2) {
                         const int f1 = otherE[(size_t)d1], f2 = otherE[(size_t)d2];
@@ -1463,9 +1468,9 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
                 co += (double)a.size();
             }
             const double all = 0.5 * (double)e.n_f * (e.n_f + 1.0);
-            e.explicit_pairs = !e.h_row_of.empty() || co < 0.5 * all;
+            e.explicit_pairs = !e.h_row_of.empty() || (list_pairs && co < 0.5 * all);
             if (const char* pv = getenv("VMM_BA_PAIRS"))
-                e.explicit_pairs = !e.h_row_of.empty() || !strcmp(pv, "explicit");
+                e.explicit_pairs = !e.h_row_of.empty() || (list_pairs && !strcmp(pv, "explicit"));
             if (e.explicit_pairs)
                 partners.swap(adj);
             (void)mark;
