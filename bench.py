@@ -43,6 +43,11 @@ def parse():
     ap.add_argument("--collective", choices=["rccl", "callback"], default="rccl",
                     help="N > 1: 'rccl' = the library's own ncclAllReduce recorded into the iteration graph "
                          "(vmm_ba_enable_rccl); 'callback' = host callback into torch.distributed per collective")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for N > 1.  'nccl' (= RCCL over xGMI) is what the driver's multi-GPU run "
+                         "uses.  'gloo' rehearses the same N-rank harness (sharding, fences, MAX-reduced elapsed time) on ONE "
+                         "GPU: every rank uses device 0 and the collectives go through the host callback "
+                         "(--collective callback is implied); its value prices the harness, not the links")
     ap.add_argument("--elimination", choices=["auto", "cams", "tags"], default="auto")
     ap.add_argument("--workload", choices=["ba", "incremental"], default="ba",
                     help="'ba' (default): the LM loop of one full-size bundle adjustment -- the metric of BASELINE.json. "
@@ -133,6 +138,10 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible")
+    gloo = a.backend == "gloo"
+    if gloo:
+        local_rank = 0          # all ranks share the one GPU of the box
+        a.collective = "callback"
     torch.cuda.set_device(local_rank)
     # VMM_BA_FORCE_COLLECTIVES=1 (test hook) runs the multi-rank code path with a single rank
     use_dist = world > 1 or os.environ.get("VMM_BA_FORCE_COLLECTIVES") == "1"
@@ -141,7 +150,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     overrides = {}
     if a.visibility < 1.0:
@@ -205,12 +217,20 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert done == a.steps, (done, a.steps)
 
     line = None
+    # what the scene is: BASELINE's configurations are visibility-1.0 walls; --visibility / --neighbors / --wall-rows
+    # give secondary scenes and are named as such
+    standard_scene = a.visibility == 1.0 and not a.neighbors and a.wall_rows == 0
+    if a.neighbors:
+        scene_desc = "close-up scene: every image sees its %d..%d nearest tags%s" % (
+            a.neighbors[0], a.neighbors[1], (", tags in %d row(s)" % a.wall_rows) if a.wall_rows > 0 else "")
+    else:
+        scene_desc = "visibility %.2f" % a.visibility
     if rank == 0:
         n_obs_total = s.n_obs
         it_per_s = a.steps / elapsed
@@ -221,10 +241,10 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if precision == "f64" else "f32 J^T J accumulation, f64 residuals/gradient/reduced system/solve",
             "data": "synthetic",
-            "config": {"workload": "configs[%d]: %d images x %d tags, visibility %.2f, %d tag observations "
+            "config": {"workload": "configs[%d]%s: %d images x %d tags, %s, %d tag observations "
                                    "(%d corner residual blocks), %s, perturbed initial guess"
-                                   % (a.config - 1, n_cams, n_tags, a.visibility, n_obs_total, 4 * n_obs_total,
-                                      "Huber(1.0)" if robust else "no loss"),
+                                   % (a.config - 1, "" if standard_scene else " (modified scene)", n_cams, n_tags, scene_desc,
+                                      n_obs_total, 4 * n_obs_total, "Huber(1.0)" if robust else "no loss"),
                        "eliminated_family": "cameras" if elim_cams else "tags",
                        "reduced_system_order": 6 * (n_tags if elim_cams else n_cams),
                        "elimination_form": "block-sparse (k_schur_pairs)" if last.get("block_sparse") else "dense Z + MFMA rank-k",
@@ -259,8 +279,11 @@ def main():
             # cost-only pass (vmm_ba_cost): no longer part of an LM iteration, reported for its HBM roofline
             "eval_cost": {"ms": kt["cost_ms"], "bound": "hbm", "alg": 72.0 * n_obs, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s"},
-            # S = Z^T Z, lower triangle incl. the rhs row: (n+1)(n+2)/2 * K multiply-adds
-            "schur_syrk": {"ms": kt["syrk_ms"], "bound": "mfma", "alg": 1.0 * n_aug * (n_aug + 1) * k_dim,
+            # dense form: S = Z^T Z, lower triangle incl. the rhs row: (n+1)(n+2)/2 * K multiply-adds.  Block-sparse
+            # form (k_schur_pairs): the flops of the terms that exist (2 * 36 * 6 per term of a pair, counted by the
+            # library when it builds the plan) -- pricing it with the dense count would credit work that is not done
+            "schur_syrk": {"ms": kt["syrk_ms"], "bound": "mfma",
+                           "alg": float(kt["schur_flops"]) if kt.get("schur_sparse") else 1.0 * n_aug * (n_aug + 1) * k_dim,
                            "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"},
             # Cholesky n^3/3 + forward/backward substitution 2 n^2
             "cholesky_solve": {"ms": kt["cholesky_ms"], "bound": "mfma",
@@ -277,7 +300,9 @@ def main():
         traffic = {}
         tname = "r03_pmc_traffic.json"
         tpath = os.path.join(ROOT, "profiles", tname)
-        if a.config == 2 and a.visibility == 1.0 and os.path.exists(tpath):
+        # the committed counters are of the headline command only: dense elimination of the standard 500 x 200 scene
+        if (a.config == 2 and standard_scene and not kt.get("schur_sparse") and not last.get("tree_ordering")
+                and precision == "f64" and os.path.exists(tpath)):
             with open(tpath) as f:
                 bpl = json.load(f)["bytes_per_launch"]
             traffic = {"eval_jacobian": bpl.get("eval_jacobian"), "eval_cost": bpl.get("eval_cost"),
@@ -294,7 +319,8 @@ def main():
                                     % (n_blk * (n_blk + 1) // 2 + n_blk, n_blk)) if dataflow else
                                    ("cholesky_solve = %d x k_chol_step + k_chol_dataflow on the last block columns + "
                                     "k_backsolve_chain" % max(n_blk - 34, 0)),
-                 "schur_syrk": "k_syrk_streamk", "eval_jacobian": "k_eval_both + k_reduce_pose", "eval_cost": "k_cost"}
+                 "schur_syrk": "k_form_z<SPARSE> + k_schur_pairs" if kt.get("schur_sparse") else "k_syrk_streamk + k_reduce_partials",
+                 "eval_jacobian": "k_eval_both + k_reduce_pose", "eval_cost": "k_cost"}
         line["roofline"] = {"kernel": names.get(dom, dom), "bound": d["bound"], "achieved": d["achieved"],
                             "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": traffic.get(dom),
                             "traffic_source": ("profiles/%s (committed rocprofv3 --pmc passes of this command; not "
@@ -322,6 +348,7 @@ def main():
         for k in ("eval_cost", "eval_jacobian"):
             if kern[k]["ms"] > 0:
                 line["kernels"][k]["residual_evals_per_sec"] = 4.0 * n_obs / (kern[k]["ms"] * 1e-3)
+        line["kernels"]["schur_syrk"]["kernel"] = names["schur_syrk"]
         line["kernels"]["form_z"] = {"ms": kt["form_z_ms"]}
         line["kernels"]["backsub"] = {"ms": kt["backsub_ms"]}
         line["kernels"]["lm_iteration_enqueued"] = {"ms": kt["lm_iteration_ms"]}

@@ -38,8 +38,9 @@ def regs_of(text):
 def assembly(stamps):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
-        cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "--offload-device-only",
-               "-S", SRC, "-o", out]
+        # the flags of visual_marker_mapping_amd/csrc/Makefile for this file (FLAGS + CHOL_FLAGS)
+        cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-mllvm",
+               "-amdgpu-mfma-vgpr-form=1", "--offload-device-only", "-S", SRC, "-o", out]
         if stamps:
             cmd.insert(1, "-DVMM_STAMPS")
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,

@@ -13,18 +13,32 @@ n = 1200
 B = rng.standard_normal((n, n)); A = B @ B.T + n * np.eye(n); b = rng.standard_normal(n)
 for rep in range(3):
     x, info = eng.dense_spd_solve(A, b)
-    st = (C.c_ulonglong * (32 * 64))()
+    st = (C.c_ulonglong * (32 * 128))()
     _lib.lib().vmm_ba_debug_read_df_stamps(st)
-    s = np.array(list(st), dtype=np.int64).reshape(32, 64)
+    s = np.array(list(st), dtype=np.int64).reshape(32, 128)
     t0 = s[0, 0]
     print("rep", rep, "err", np.abs(x - np.linalg.solve(A, b)).max())
     for j in range(19):
         r = (s[j, :10] - t0) / 100.0   # us
         d = (s[j, 12:14] - t0) / 100.0
         print("j=%2d start %7.2f [slice 6 seen %7.2f slice 7 seen %7.2f] consumed %7.2f rounds %s" % (j, r[0], d[0], d[1], r[1], " ".join("%7.2f" % v for v in r[2:10])))
+    for j in (5, 6):
+        print("j=%d: slices of panel %d published at %s" % (j, j - 1, " ".join("%7.2f" % v for v in (s[j - 1, 2:10] - t0) / 100.0)))
+        print("      seen by workgroup (%d, %d) at      %s" % (j, j + 1, " ".join("%7.2f" % v for v in (s[j, 14:22] - t0) / 100.0)))
+        print("      its wave 1 (rows %d) saw its slice at %s" % (j + 1, " ".join("%7.2f" % v for v in (s[j, 64:72] - t0) / 100.0)))
+        print("      barrier behind the staging passed at %s" % " ".join("%7.2f" % v for v in (s[j, 80:88] - t0) / 100.0))
+        print("      worker 0 issued its MFMAs of it at   %s" % " ".join("%7.2f" % v for v in (s[j, 72:80] - t0) / 100.0))
+        print("      worker 1                             %s" % " ".join("%7.2f" % v for v in (s[j, 88:96] - t0) / 100.0))
     j = 5
-    p = s[j, 40:46] - s[j, 40]
-    wk = s[j, 48:55] - s[j, 48]
-    print("panel 5 round J0=16 (s_memtime, unfenced: indicative): pivot wave: A-wait %d 8x8 Cholesky %d B-wait %d scale %d C-wait %d" % (p[1]-p[0], p[2]-p[1], p[3]-p[2], p[4]-p[3], p[5]-p[4]))
-    print("     worker 0: phase1 %d A-wait %d phase2 %d B-wait %d phase3 %d C-wait %d" % (wk[1]-wk[0], wk[2]-wk[1], wk[3]-wk[2], wk[4]-wk[3], wk[5]-wk[4], wk[6]-wk[5]))
+    p = s[j, 40:45] - s[j, 40]
+    wk = s[j, 48:53] - s[j, 48]
+    print("panel 5 round J0=16 (s_memtime, unfenced: indicative): pivot wave: 8x8 Cholesky %d B-wait %d scale + next pivot block %d C-wait %d" % (p[1]-p[0], p[2]-p[1], p[3]-p[2], p[4]-p[3]))
+    p1 = s[j, 32:37] - s[j, 32]
+    w1 = s[j, 24:29] - s[j, 24]
+    print("     pivot wave 1: 8x8 Cholesky %d B-wait %d scale + publish %d C-wait %d" % (p1[1]-p1[0], p1[2]-p1[1], p1[3]-p1[2], p1[4]-p1[3]))
+    print("     worker 1: phase 2 %d B-wait %d phase 3 %d C-wait %d" % (w1[1]-w1[0], w1[2]-w1[1], w1[3]-w1[2], w1[4]-w1[3]))
+    print("     raw s_memtime relative to pivot wave 0's round start: P0 %s | P1 %s | W0 %s | W1 %s" % (s[j, 40:45] - s[j, 40], s[j, 32:37] - s[j, 40], s[j, 48:53] - s[j, 40], s[j, 24:29] - s[j, 40]))
+    q = s[j, 56:59] - s[j, 42]
+    print("     after B: scaled %d, rows written + Nd read %d, Gram done %d" % (q[0], q[1], q[2]))
+    print("     worker 0: phase 2 %d B-wait %d phase 3 %d C-wait %d" % (wk[1]-wk[0], wk[2]-wk[1], wk[3]-wk[2], wk[4]-wk[3]))
 PY

@@ -1476,16 +1476,21 @@ __device__ __forceinline__ void chol_inverse_wg(const double* __restrict__ Ldk, 
 // ends every other spin; the factorisation is then reported as failed (NaN poisoning + lin_fail).
 // ------------------------------------------------------------------------------------------------
 constexpr int kDfSlice = 2 * 8 * 64;         // granules (8 bytes each) per published slice
+// LDS row stride (doubles) of the dataflow kernel's 64x8 panel buffers and 8x8 blocks: EVEN, so a row starts 16-byte
+// aligned and is read / written two entries per instruction (the pivot waves' LDS round trips are on the critical path:
+// 4 instead of 8 per row); 10: a 16-lane group of ds_read_b128 covers all 64 banks, the workers' ds_read_b64 operand
+// fetches (16 rows x 2 columns per half wave) stay conflict-free
+constexpr int kPsD = 10;
 constexpr unsigned kDfSpinDefault = 1u << 21;   // polls of ~0.3 us each before giving up
 constexpr int kDfXs = 8 * kLdsRow;            // doubles per staged slice, k-major [8][kLdsRow]
 // doubles: 73 KB used, declared as 84 KB.  The copy of the diagonal factor that the block inverse reads (64 x kLd + 64,
 // diagonal-only role, after the last round) lives in the panel / slice buffers, which are dead by then.  84 KB: two
 // of these workgroups never share a CU (every wave alone on its SIMD), while a rank-k update workgroup (72 KB) still
 // fits on the same CU beside a factorisation workgroup that is waiting for its block column (156 of 160 KB).
-constexpr int kDfSmemUsed = 64 * kLdT + 4 * 64 * kPs + 64 + 4 * kDfXs;
+constexpr int kDfSmemUsed = 64 * kLdT + 4 * 64 * kPsD + 64 + 2 * 8 * kPsD + 4 * kDfXs;
 constexpr int kDfSmem = 84 * 1024 / 8;
 static_assert(kDfSmemUsed <= kDfSmem, "dataflow LDS layout");
-static_assert(4 * 64 * kPs + 64 + 4 * kDfXs >= 64 * kLd + 64, "the inverse's staging area must fit into the dead buffers");
+static_assert(4 * 64 * kPsD + 64 + 4 * kDfXs >= 64 * kLd + 64, "the inverse's staging area must fit into the dead buffers");
 
 struct DfArgs {
     LmCtl* ctl;
@@ -1519,7 +1524,7 @@ __device__ __forceinline__ double df_value(const unsigned long long lo, const un
 }
 
 #ifdef VMM_STAMPS
-__device__ unsigned long long g_df_stamps[32][64];   // [block column][slot]: s_memrealtime (100 MHz) / s_memtime
+__device__ unsigned long long g_df_stamps[32][128];   // [block column][slot]: s_memrealtime (100 MHz) / s_memtime
 #define DF_RT(slot)                                                                              \
     do {                                                                                         \
         if (stamp_on && lane == 0)                                                               \
@@ -1527,12 +1532,12 @@ __device__ unsigned long long g_df_stamps[32][64];   // [block column][slot]: s_
     } while (0)
 #define DF_CY(slot)                                                                              \
     do {                                                                                         \
-        if (stamp_on && lane == 0)                                                               \
-            g_df_stamps[stamp_j][slot] = __builtin_amdgcn_s_memtime();                           \
+        if (stamp_cy && lane == 0)                                                               \
+            g_df_stamps[stamp_j][(slot) - stamp_off] = __builtin_amdgcn_s_memtime();             \
     } while (0)
 extern "C" int vmm_ba_debug_read_df_stamps(unsigned long long* out)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_df_stamps), sizeof(unsigned long long) * 32 * 64);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_df_stamps), sizeof(unsigned long long) * 32 * 128);
 }
 #else
 #define DF_RT(slot)
@@ -1540,6 +1545,40 @@ extern "C" int vmm_ba_debug_read_df_stamps(unsigned long long* out)
 #endif
 
 namespace df2 {
+
+// chol8 (above) for the dataflow kernel: the block at D has row stride kPsD and is read two entries at a time; the
+// validity test is off the chain altogether -- a non-positive or non-finite pivot gives NaN (v_rsq_f64 of a negative
+// number, 0 * inf in the correction), every later entry of the factor inherits it, and ok is read off the last reciprocal
+__device__ __forceinline__ void chol8_df(const double* __restrict__ D, Piv8& p)
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; c += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(D + r * kPsD + c);
+            p.l[tri8(r, c)] = v.x;
+            if (c + 1 <= r)
+                p.l[tri8(r, c + 1)] = v.y;
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double t = p.l[tri8(j, j)];
+        const double y0 = __builtin_amdgcn_rsq(t);
+        const double e = fma(-t * y0, y0, 1.0);
+        const double inv = fma(y0 * e, fma(e, 0.375, 0.5), y0);
+        p.inv[j] = inv;
+        p.l[tri8(j, j)] = t * inv;
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i)
+            p.l[tri8(i, j)] *= inv;
+#pragma unroll
+        for (int c = j + 1; c < 8; ++c)
+#pragma unroll
+            for (int i = c; i < 8; ++i)
+                p.l[tri8(i, c)] = fma(-p.l[tri8(i, j)], p.l[tri8(c, j)], p.l[tri8(i, c)]);
+    }
+    p.ok = isfinite(p.inv[7]);
+}
 
 // tile tables: worker 0 = D lower tiles (row-major) + T(0,0..2); worker 1 = T(0,3) + T(1..3, 0..3)
 __device__ __forceinline__ constexpr bool is_t(int wk, int i) { return wk == 0 ? i >= 10 : true; }
@@ -1555,35 +1594,59 @@ __device__ __forceinline__ constexpr int tile_j(int wk, int i)
         return i >= 10 ? i - 10 : i - tile_i(0, i) * (tile_i(0, i) + 1) / 2;
     return i == 0 ? 3 : (i - 1) % 4;
 }
-// phase of tile i in the rank-8 update applied during the round of columns J0.. (pivot tile column tc = J0 >> 4):
-// 0 = not touched, 1 = the pivot tile, 2 = its tile column (and the first remaining tiles), 3 = the others
-__device__ __forceinline__ constexpr int phase_of(int wk, int i, int tc, bool has_t)
+// Round r factors columns J0 = 8 r .. J0 + 7 of the block column.  The pivot waves form the NEXT pivot block themselves
+// (pivot_round: the 8x8 Gram product of the eight scaled rows below the pivot block), so what the pivot chain needs from
+// the workers before it can scale its rows is: the columns of this round for all rows below the pivot block (the tiles of
+// the pivot tile column tc = r >> 1) and the diagonal 8x8 block of round r + 1 as it is BEFORE this round's update (the
+// Gram product is subtracted from it).  That block sits in the pivot tile for even r and in the next diagonal tile for
+// odd r.
+// Phase of tile i in the rank-8 update with the columns of round r - 1, applied during round r:
+//   0  not touched (left of the pivot tile column; the diagonal tile of an odd round: what is left of it is the pivot
+//      block the pivot waves compute themselves)
+//   1  round 0 only: the tile that holds the first pivot block (one more barrier: the 8x8 Cholesky starts behind it)
+//   2  needed by the pivot waves before they scale, then as many of the others as fit beside the 8x8 Cholesky
+//   3  the others, beside the scaling
+#ifndef VMM_DF_FILL2
+#define VMM_DF_FILL2 4
+#endif
+constexpr int kFill2 = VMM_DF_FILL2;
+__device__ __forceinline__ constexpr bool urgent_tile(int wk, int i, int r)
+{
+    const int tc = r >> 1, tj = tile_j(wk, i), ti = tile_i(wk, i);
+    const bool diag = !is_t(wk, i) && ti == tj;
+    if (tj == tc)
+        return !(diag && (r & 1));
+    return (r & 1) && diag && tj == tc + 1;
+}
+__device__ __forceinline__ constexpr int phase_of(int wk, int i, int r, bool has_t)
 {
     if (is_t(wk, i) && !has_t)
         return 0;
-    const int tj = tile_j(wk, i), ti = tile_i(wk, i);
-    if (tj < tc)
+    const int tc = r >> 1, tj = tile_j(wk, i), ti = tile_i(wk, i);
+    const bool diag = !is_t(wk, i) && ti == tj;
+    if (tj < tc || (tj == tc && diag && (r & 1)))
         return 0;
-    if (tj == tc)
-        return (!is_t(wk, i) && ti == tc) ? 1 : 2;
-    // remaining tiles: fill phase 2 up to seven tiles per worker (14 MFMAs ~ the 8x8 Cholesky beside it)
-    int n_col = 0, rank = 0;
+    if (urgent_tile(wk, i, r))
+        return (r == 0 && diag) ? 1 : 2;
+    // remaining tiles: fill phase 2 up to kFill2 tiles per worker: operand loads + 2 MFMAs per tile + the publication of
+    // the urgent ones must end before the 8x8 Cholesky beside them does (~1100 cycles), or the pivot chain waits
+    int n_urgent = 0, rank = 0;
     for (int k = 0; k < 13; ++k) {
         if (is_t(wk, k) && !has_t)
             continue;
-        if (tile_j(wk, k) == tc && !(!is_t(wk, k) && tile_i(wk, k) == tc))
-            ++n_col;
-        if (tile_j(wk, k) > tc && k < i)
+        if (urgent_tile(wk, k, r))
+            ++n_urgent;
+        else if (tile_j(wk, k) >= tc && !(tile_j(wk, k) == tc) && k < i)
             ++rank;
     }
-    return (n_col + rank < 7) ? 2 : 3;
+    return (n_urgent + rank < kFill2) ? 2 : 3;
 }
 
 struct Ops {   // MFMA operands of one k-step: A of the diagonal block's tile rows, A of the block below, B
     double ad[4], at[4], b[4];
 };
 
-// operands of the rank-8 update with the scaled columns in pd / pt (row-major, stride kPs); rows < m are masked
+// operands of the rank-8 update with the scaled columns in pd / pt (row-major, stride kPsD); rows < m are masked
 template <int WK, bool HAS_T>
 __device__ __forceinline__ void load_ops_panel(const double* pd, const double* pt, const int m, const int fr, const int fk,
                                                Ops (&o)[2])
@@ -1593,11 +1656,11 @@ __device__ __forceinline__ void load_ops_panel(const double* pd, const double* p
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int row = 16 * t + fr;
-            const double v = pd[row * kPs + 4 * ks + fk];
+            const double v = pd[row * kPsD + 4 * ks + fk];
             const double vm = (row >= m) ? v : 0.0;
             o[ks].b[t] = vm;
             o[ks].ad[t] = (WK == 0) ? -vm : 0.0;
-            o[ks].at[t] = (HAS_T && (WK == 1 || t == 0)) ? -pt[row * kPs + 4 * ks + fk] : 0.0;
+            o[ks].at[t] = (HAS_T && (WK == 1 || t == 0)) ? -pt[row * kPsD + 4 * ks + fk] : 0.0;
         }
 }
 
@@ -1635,32 +1698,60 @@ __device__ __forceinline__ void publish_tile(const double4_t (&acc)[13], double*
 {
     constexpr int ti = tile_i(WK, I);
     if (fr >= cj && fr < cj + kPw) {
-        double* dst = (is_t(WK, I) ? pt : pd) + (16 * ti + fk) * kPs + (fr - cj);
+        double* dst = (is_t(WK, I) ? pt : pd) + (16 * ti + fk) * kPsD + (fr - cj);
         dst[0] = acc[I][0];
-        dst[4 * kPs] = acc[I][1];
-        dst[8 * kPs] = acc[I][2];
-        dst[12 * kPs] = acc[I][3];
+        dst[4 * kPsD] = acc[I][1];
+        dst[8 * kPsD] = acc[I][2];
+        dst[12 * kPsD] = acc[I][3];
     }
 }
 
-// one phase of a worker: the tiles of that phase are updated (UPDATE: not in the first round of a panel, whose
-// accumulators are complete) and, in phases 1 and 2, the tiles of the pivot tile column are published
-template <int WK, bool HAS_T, int J0, int PHASE, bool UPDATE, int... Is>
-__device__ __forceinline__ void worker_phase(double4_t (&acc)[13], const Ops (&o)[2], double* pd, double* pt, const int fr,
-                                             const int fk, std::integer_sequence<int, Is...>)
+// 8x8 quadrant (QR, QC) of tile I -> dst (row stride kPsD): the first pivot block of a panel and the diagonal block the
+// pivot waves subtract their Gram product from
+template <int I, int QR, int QC>
+__device__ __forceinline__ void publish_quadrant(const double4_t (&acc)[13], double* dst, const int fr, const int fk)
 {
-    constexpr int tc = J0 >> 4;
-    auto one = [&](auto idx) {
+    if (fr >= 8 * QC && fr < 8 * QC + 8) {
+        double* d = dst + fk * kPsD + (fr - 8 * QC);
+        d[0] = acc[I][2 * QR];
+        d[4 * kPsD] = acc[I][2 * QR + 1];
+    }
+}
+
+// one phase of a worker in round R8 (columns 8 R8 ..): the tiles of that phase are updated (UPDATE: not in the first round
+// of a panel, whose accumulators are complete); the tiles of the pivot tile column are published, and so are the first
+// pivot block (round 0, -> pb) and the diagonal block of the next round before this round's update (-> nd)
+template <int WK, bool HAS_T, int R8, int PHASE, bool UPDATE, int... Is>
+__device__ __forceinline__ void worker_phase(double4_t (&acc)[13], const Ops (&o)[2], double* pd, double* pt, double* pb,
+                                             double* nd, const int fr, const int fk, std::integer_sequence<int, Is...>)
+{
+    constexpr int tc = R8 >> 1;
+    // all MFMAs of the phase first, the urgent tiles leading: a publication right behind its own tile's MFMAs would wait
+    // for the matrix pipeline to drain once per tile
+    auto upd = [&](auto idx, auto urgent_pass) {
         constexpr int I = decltype(idx)::value;
-        constexpr int ph = phase_of(WK, I, tc, HAS_T);
-        if constexpr (ph == PHASE) {
-            if constexpr (UPDATE)
-                mfma_tile<WK, I>(acc, o);
-            if constexpr (tile_j(WK, I) == tc)
-                publish_tile<WK, I>(acc, pd, pt, J0 & 15, fr, fk);
+        constexpr bool U = decltype(urgent_pass)::value;
+        if constexpr (UPDATE && phase_of(WK, I, R8, HAS_T) == PHASE && urgent_tile(WK, I, R8) == U)
+            mfma_tile<WK, I>(acc, o);
+    };
+    (upd(std::integral_constant<int, Is>{}, std::true_type{}), ...);
+    (upd(std::integral_constant<int, Is>{}, std::false_type{}), ...);
+    auto pub = [&](auto idx) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (phase_of(WK, I, R8, HAS_T) == PHASE) {
+            constexpr int ti = tile_i(WK, I), tj = tile_j(WK, I);
+            constexpr bool diag = !is_t(WK, I) && ti == tj;
+            if constexpr (tj == tc)
+                publish_tile<WK, I>(acc, pd, pt, (8 * R8) & 15, fr, fk);
+            if constexpr (diag && R8 == 0 && tj == 0)
+                publish_quadrant<I, 0, 0>(acc, pb, fr, fk);
+            if constexpr (diag && R8 < 7 && !(R8 & 1) && tj == tc)
+                publish_quadrant<I, 1, 1>(acc, nd, fr, fk);
+            if constexpr (diag && R8 < 7 && (R8 & 1) && tj == tc + 1)
+                publish_quadrant<I, 0, 0>(acc, nd, fr, fk);
         }
     };
-    (one(std::integral_constant<int, Is>{}), ...);
+    (pub(std::integral_constant<int, Is>{}), ...);
 }
 
 template <int WK, bool HAS_T, int... Is>
@@ -1739,11 +1830,38 @@ __device__ __forceinline__ bool wait_slice(const unsigned long long* sl, const i
     }
 }
 
+// The slices a workgroup waits for while their producer is still at work (the panel right before mine).  A look at a slice
+// is a round trip to the level the XCDs share (~1.1 us under this kernel's traffic) and the producer publishes one every
+// ~0.85 us, so ONE look at a time cannot keep up: the look at slice s+1 must be on its way before slice s has been seen.
+// Both the slice waited for (g) and the next one (gn, requested ahead by the caller) are looked at again each time their
+// previous look comes back stale, alternately, so each is sampled once per round trip, half a round trip apart, and the
+// next slice is usually complete in its registers when the current one has been staged.
+// (Measured before: the copy requested two slices ahead was always stale, every slice then cost a fresh round trip after its
+// predecessor, and each block column started 2.3 us behind the last slice of the previous one, 3 us with shorter rounds.)
+__device__ __forceinline__ bool wait_slice_pair(const unsigned long long* sl, const unsigned long long* sl_next, const int lane,
+                                                const unsigned epoch, const unsigned* abort_word, SliceRegs& g, SliceRegs& gn,
+                                                const unsigned kDfSpinLimit)
+{
+    for (unsigned n = 0;;) {
+        if (kDfSpinLimit != 1u && __all(slice_valid(g, epoch)))   // a limit of 1 (debugging) gives up even on valid data
+            return true;
+        if (++n >= kDfSpinLimit)
+            return false;
+        if ((n & 63u) == 63u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)
+            return false;
+        issue_slice(sl, lane, g);
+        if (sl_next && !__all(slice_valid(gn, epoch)))
+            issue_slice(sl_next, lane, gn);
+    }
+}
+
 struct Lds {
     double* RA;     // D-only role: L^T (stride kLdT); others: result tile (stride kLd)
-    double* Pd;     // [2][64][kPs] panel columns of the diagonal block's rows (ping-pong between rounds)
+    double* Pd;     // [2][64][kPsD] panel columns of the diagonal block's rows (ping-pong between rounds)
     double* Pt;     // the same for the rows below
     double* invd;
+    double* Pb;     // [8][kPsD] the pivot block of the current round (round 0: from the workers; then from the pivot waves)
+    double* Nd;     // [8][kPsD] the diagonal block of the next round before this round's update (from the workers)
     double* Xs;     // [2 buffers][J | R][8][kLdsRow] staged slices of earlier panels
     int stamp_j;    // diagnostic build: block column whose (j, j+1) workgroup records time stamps (else -1)
 };
@@ -1758,25 +1876,34 @@ struct SliceMap {
     }
 };
 
-// ---- the pivot waves' program: sweeps during the earlier panels, then 8 x (8x8 Cholesky, scale rows) ----
-// Barriers: one per consumed slice, three per round -- the same sequence as worker_path.
+// ---- the pivot waves' program: sweeps during the earlier panels, then 8 x (8x8 Cholesky, scale rows, next pivot block) ----
+// Barriers: one per consumed slice, then per round (A, round 0 only) B, C -- the same sequence as worker_path.
+//   A  the first pivot block of the panel is in Pb (from the workers' accumulators)
+//   B  all rows below the pivot block, columns J0..J0+7, are in pdc / ptc and the next diagonal block in Nd
+//   C  the scaled columns are in pdc / ptc, the next pivot block in Pb
+// The pivot chain is 8x8 Cholesky -> B -> scale the rows -> next pivot block = Nd - X X^T for the eight scaled rows X right
+// below the pivot block (wave 0, lane = one entry of the block, the rows exchanged through pdc: same wave, no barrier)
+// -> C -> 8x8 Cholesky; the workers' rank-8 update of the pivot tile column runs beside the 8x8 Cholesky instead of in
+// front of it (until round 3 this was a third phase of ~640 cycles per round: MFMA update of the pivot tile, LDS, barrier).
 template <int J0, bool HAS_T>
 __device__ __forceinline__ void pivot_round(const int w, const int lane, const Lds& m, bool& ok, unsigned long long* gs,
                                             const unsigned epoch)
 {
-    double* pdc = m.Pd + ((J0 >> 3) & 1) * 64 * kPs;
-    double* ptc = m.Pt + ((J0 >> 3) & 1) * 64 * kPs;
+    double* pdc = m.Pd + ((J0 >> 3) & 1) * 64 * kPsD;
+    double* ptc = m.Pt + ((J0 >> 3) & 1) * 64 * kPsD;
     const bool active = w == 0 || HAS_T;
 #ifdef VMM_STAMPS
     const bool stamp_on = m.stamp_j >= 0 && w == 0;
+    const bool stamp_cy = m.stamp_j >= 0;
+    const int stamp_off = w == 0 ? 0 : 8;
     const int stamp_j = m.stamp_j;
 #endif
+    if (J0 == 0)
+        __syncthreads();   // A: the first pivot block is in Pb
     if (J0 == 16) DF_CY(40);
-    __syncthreads();   // phase 1 done: the pivot block is in pdc
-    if (J0 == 16) DF_CY(41);
     Piv8 p;
     if (active) {
-        chol8(pdc + J0 * kPs, p);
+        chol8_df(m.Pb, p);
         // the factor is complete BEFORE the barrier: left alone, the compiler sinks its arithmetic behind the barrier
         // and the 8x8 Cholesky no longer overlaps with the workers' phase 2 (measured with the stamps build)
 #pragma unroll
@@ -1786,17 +1913,22 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
         for (int k = 0; k < 8; ++k)
             asm volatile("" : "+v"(p.inv[k]));
     }
+    if (J0 == 16) DF_CY(41);
+    __syncthreads();   // B: all rows of columns J0..J0+7 are in pdc / ptc, the next diagonal block in Nd
     if (J0 == 16) DF_CY(42);
-    __syncthreads();   // phase 2 done: all rows of columns J0..J0+7 are in pdc / ptc
-    if (J0 == 16) DF_CY(43);
     if (active) {
-        double* row = (w == 0 ? pdc : ptc) + lane * kPs;
+        double* row = (w == 0 ? pdc : ptc) + lane * kPsD;
         double x[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            x[q] = row[q];
-        scale8(x, p);   // x = a L8^{-T}
-        auto publish = [&]() {
+        for (int q = 0; q < 8; q += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(row + q);
+            x[q] = v.x;
+            x[q + 1] = v.y;
+        }
+        if (w == 1) {
+            scale8(x, p);   // x = a L8^{-T}
+            // the rows below leave for the other workgroups first (the longest latency of the round; holding them
+            // back behind the barrier in all rounds but the last was measured slower) ...
             const unsigned long long tag = (unsigned long long)epoch << 32;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -1806,28 +1938,58 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
                 __hip_atomic_store(gs + 512 + q * 64 + lane, tag | (bits >> 32), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
-        };
-        if (w == 1) {
-            // the rows below leave for the other workgroups first (the longest latency of the round; holding them
-            // back behind the barrier in all rounds but the last was measured slower) ...
-            publish();
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                row[q] = x[q];
+            for (int q = 0; q < 8; q += 2)
+                *reinterpret_cast<double2*>(row + q) = make_double2(x[q], x[q + 1]);
         } else {
             ok = ok && p.ok;
-            if (lane - J0 >= kPw) {
+            // Wave 0 is the pivot chain.  The next pivot block: entry (gi, gj) = Nd - sum_q X[gi][q] X[gj][q] over the
+            // scaled rows X = rows J0+8 .. J0+15, which lanes J0+8 .. J0+15 of this very wave produce (LDS operations of a
+            // wave stay in order: no barrier).  Column q of a row is final after step q of the scaling, so it is written
+            // and the two entries of it a lane needs are requested back right there: the LDS round trips run beside the
+            // remaining steps instead of behind the last one.  Every lane writes its row -- rows up to the pivot block hold
+            // nothing anybody reads (the workers mask them, load_ops_panel).
+            constexpr bool NEXT = J0 + kPw < 64;
+            const int gi = lane >> 3, gj = lane & 7;
+            const double* xi = pdc + (J0 + kPw + gi) * kPsD;
+            const double* xj = pdc + (J0 + kPw + gj) * kPsD;
+            double sacc = NEXT ? m.Nd[gi * kPsD + gj] : 0.0;
+            double vi[8], vj[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                x[q] *= p.inv[q];
+#pragma unroll
+                for (int c = q + 1; c < 8; ++c)
+                    x[c] = fma(-x[q], p.l[tri8(c, q)], x[c]);
+                row[q] = x[q];
+                if (NEXT) {
+                    vi[q] = xi[q];
+                    vj[q] = xj[q];
+                }
+            }
+#ifdef VMM_STAMPS
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                asm volatile("" : "+v"(x[q]));
+            if (J0 == 16) DF_CY(56);
+#endif
+            if (NEXT) {
+                if (J0 == 16) DF_CY(57);
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    row[q] = x[q];
+                    sacc = fma(-vi[q], vj[q], sacc);
+#ifdef VMM_STAMPS
+                asm volatile("" : "+v"(sacc));
+                if (J0 == 16) DF_CY(58);
+#endif
+                m.Pb[gi * kPsD + gj] = sacc;
             }
         }
+        if (J0 == 16) DF_CY(43);
+        __syncthreads();   // C: the scaled columns are in pdc / ptc, the next pivot block in Pb
         if (J0 == 16) DF_CY(44);
-        __syncthreads();   // phase 3 done: the scaled columns are in pdc / ptc
-        if (J0 == 16) DF_CY(45);
         DF_RT(2 + (J0 >> 3));
-        // ... what only this workgroup's final write-back needs is stored behind the barrier, beside the workers'
-        // phase 1 of the next round
+        // ... what only this workgroup's final write-back needs is stored behind the barrier, beside the next 8x8 Cholesky
         if (w == 1) {
             double* rr = m.RA + lane * kLd + J0;
 #pragma unroll
@@ -1855,7 +2017,7 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
             }
         }
     } else {
-        __syncthreads();   // phase 3 done (idle pivot wave of the diagonal-only role)
+        __syncthreads();   // C (idle pivot wave of the diagonal-only role)
     }
 }
 
@@ -1865,36 +2027,55 @@ template <bool HAS_T, bool TREE>
 __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const int lane, const int j, const int R,
                                            const Lds& m, const SliceMap& sm, const unsigned epoch, int* s_timeout, bool& ok)
 {
-    const int n_it = TREE ? 8 * __popcll(df_panels(a, j)) : 8 * j;
+    const int n_it = TREE ? 8 * __popcll(df_panels(a, j)) : 8 * j;   // a multiple of 8
     if (n_it > 0) {
-        SliceRegs g;
+        // Two slices are on their way at any time (two register sets): a slice read costs a round trip to the level all
+        // XCDs share (~1.0-1.3 us) and with one request in flight that was the pace of a workgroup working off panels that are
+        // long complete -- slower than they are produced since the rounds got shorter, so every block column started later
+        // behind its predecessor than the one before
+        SliceRegs ga, gb;
         const bool sweeper = w == 0 || HAS_T;
         const int my_rb = (w == 0) ? j : R;
         const unsigned char* const ord = TREE ? a.order + 64 * j : nullptr;
         // TREE: wave 1 sweeps the slices of block row R; where L(R, k) is structurally zero nobody publishes one -- zeros
         const unsigned long long mine = (!TREE || w == 0 || R >= a.n_blk) ? ~0ull : a.nz[R];
-        int k = TREE ? (int)ord[0] : 0;
-        if (sweeper && ((mine >> k) & 1ull))
-            issue_slice(sm.at(k, my_rb, 0), lane, g);
-        for (int it = 0; it < n_it; ++it) {
-            const int r = it & 7;
-            if (!TREE)
-                k = it >> 3;
+        auto panel_of = [&](const int it) { return TREE ? (int)ord[it >> 3] : (it >> 3); };
+        auto request = [&](const int it, SliceRegs& g) {
+            if (sweeper && it < n_it) {
+                const int k = panel_of(it);
+                if ((mine >> k) & 1ull)
+                    issue_slice(sm.at(k, my_rb, it & 7), lane, g);
+            }
+        };
+        auto consume = [&](const int it, SliceRegs& g, SliceRegs& gn) {
+            const int k = panel_of(it);
             const bool have = !TREE || ((mine >> k) & 1ull);
             if (sweeper) {
                 // the panel expected last (dense: the one right before mine) is swept directly instead of probed
                 const bool last_panel = TREE ? it + 8 >= n_it : k == j - 1;
-                const bool got = have ? wait_slice(sm.at(k, my_rb, r), lane, epoch, a.abort_word, last_panel, g, a.spin_limit) : true;
+                bool got = true;
+                if (have && last_panel) {
+                    // the next slice belongs to the same panel unless this is the panel's last one
+                    const bool next_too = (it & 7) != 7 && (!TREE || ((mine >> k) & 1ull));
+                    got = wait_slice_pair(sm.at(k, my_rb, it & 7), next_too ? sm.at(k, my_rb, (it & 7) + 1) : nullptr, lane, epoch,
+                                          a.abort_word, g, gn, a.spin_limit);
+                } else if (have) {
+                    got = wait_slice(sm.at(k, my_rb, it & 7), lane, epoch, a.abort_word, false, g, a.spin_limit);
+                }
 #ifdef VMM_STAMPS
                 if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 2)
                     g_df_stamps[m.stamp_j][12 + (it - (n_it - 2))] = __builtin_amdgcn_s_memrealtime();
+                if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 8)   // the last panel's slices, one by one
+                    g_df_stamps[m.stamp_j][14 + (it - (n_it - 8))] = __builtin_amdgcn_s_memrealtime();
+                if (m.stamp_j >= 0 && w == 1 && lane == 0 && it >= n_it - 8)
+                    g_df_stamps[m.stamp_j][64 + (it - (n_it - 8))] = __builtin_amdgcn_s_memrealtime();
 #endif
                 double* X = m.Xs + (it & 1) * 2 * kDfXs + (w == 0 ? 0 : kDfXs);
                 const double nan = __longlong_as_double(0x7ff8000000000000ll);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const double v = got ? df_value(g.lo[q], g.hi[q]) : nan;
-                    X[q * kLdsRow + lane] = (TREE && !have) ? 0.0 : v;
+                    const double xv = got ? df_value(g.lo[q], g.hi[q]) : nan;
+                    X[q * kLdsRow + lane] = (TREE && !have) ? 0.0 : xv;
                 }
                 if (!got && lane == 0) {
                     *s_timeout = 1;
@@ -1902,14 +2083,18 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
                 }
             }
             __syncthreads();
-            if (TREE) {
-                if (r == 7 && it + 1 < n_it)   // next panel of the list
-                    k = (int)ord[(it + 1) >> 3];
-                if (sweeper && it + 1 < n_it && ((mine >> k) & 1ull))
-                    issue_slice(sm.at(k, my_rb, (it + 1) & 7), lane, g);
-            } else if (sweeper && it + 1 < n_it) {   // the next slice is requested while the workers apply this one
-                issue_slice(sm.at((it + 1) >> 3, my_rb, (it + 1) & 7), lane, g);
-            }
+#ifdef VMM_STAMPS
+            if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 8)
+                g_df_stamps[m.stamp_j][80 + (it - (n_it - 8))] = __builtin_amdgcn_s_memrealtime();
+#endif
+        };
+        request(0, ga);
+        request(1, gb);
+        for (int it = 0; it < n_it; it += 2) {
+            consume(it, ga, gb);
+            request(it + 2, ga);   // requested while the workers apply slice it
+            consume(it + 1, gb, ga);
+            request(it + 3, gb);
         }
     }
 #ifdef VMM_STAMPS
@@ -1931,20 +2116,22 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
 // ---- a worker wave's program ----
 // SLICE (round 0 of a block column > 0 only): the "previous round" is the last slice of the previous panel, staged
 // at XJ / XR and not applied yet -- its update of the first pivot tile column comes first like any round's, so the
-// pivot waves start on the panel 16 MFMAs after the slice has arrived instead of 26 + a round.
+// pivot waves start on the panel 2 MFMAs after the slice has arrived instead of 26 + a round.
 template <int WK, int J0, bool HAS_T, bool SLICE = false>
 __device__ __forceinline__ void worker_round(const int lane, double4_t (&acc)[13], const Lds& m, const double* XJ = nullptr,
                                              const double* XR = nullptr)
 {
     static_assert(!SLICE || J0 == 0, "only the first round takes a slice");
     const int fr = lane & 15, fk = lane >> 4;
-    double* pdc = m.Pd + ((J0 >> 3) & 1) * 64 * kPs;
-    double* ptc = m.Pt + ((J0 >> 3) & 1) * 64 * kPs;
-    const double* pdp = m.Pd + (((J0 >> 3) & 1) ^ 1) * 64 * kPs;
-    const double* ptp = m.Pt + (((J0 >> 3) & 1) ^ 1) * 64 * kPs;
+    constexpr int R8 = J0 >> 3;
+    double* pdc = m.Pd + (R8 & 1) * 64 * kPsD;
+    double* ptc = m.Pt + (R8 & 1) * 64 * kPsD;
+    const double* pdp = m.Pd + ((R8 & 1) ^ 1) * 64 * kPsD;
+    const double* ptp = m.Pt + ((R8 & 1) ^ 1) * 64 * kPsD;
     constexpr bool UPD = J0 > 0 || SLICE;
 #ifdef VMM_STAMPS
-    const bool stamp_on = m.stamp_j >= 0 && WK == 0;
+    const bool stamp_cy = m.stamp_j >= 0;
+    const int stamp_off = WK == 0 ? 0 : 24;
     const int stamp_j = m.stamp_j;
 #endif
     Ops o[2];
@@ -1953,18 +2140,26 @@ __device__ __forceinline__ void worker_round(const int lane, double4_t (&acc)[13
         load_ops_slice<WK, HAS_T>(XJ, XR, fr, fk, o);
     else if (UPD)
         load_ops_panel<WK, HAS_T>(pdp, ptp, J0, fr, fk, o);
-    worker_phase<WK, HAS_T, J0, 1, UPD>(acc, o, pdc, ptc, fr, fk, Seq13{});
+    if (J0 == 0) {
+        worker_phase<WK, HAS_T, R8, 1, UPD>(acc, o, pdc, ptc, m.Pb, m.Nd, fr, fk, Seq13{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // A
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    worker_phase<WK, HAS_T, R8, 2, UPD>(acc, o, pdc, ptc, m.Pb, m.Nd, fr, fk, Seq13{});
     if (J0 == 16) DF_CY(49);
-    __syncthreads();
+    // MFMAs touch no memory, so the compiler is free to sink them behind a barrier -- and did: the rest of a round's
+    // update ran in front of the next round's urgent tiles, on the in-order matrix pipeline, ~700 cycles of every round
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();   // B
+    __builtin_amdgcn_sched_barrier(0);
     if (J0 == 16) DF_CY(50);
-    worker_phase<WK, HAS_T, J0, 2, UPD>(acc, o, pdc, ptc, fr, fk, Seq13{});
+    worker_phase<WK, HAS_T, R8, 3, UPD>(acc, o, pdc, ptc, m.Pb, m.Nd, fr, fk, Seq13{});
     if (J0 == 16) DF_CY(51);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();   // C
+    __builtin_amdgcn_sched_barrier(0);
     if (J0 == 16) DF_CY(52);
-    worker_phase<WK, HAS_T, J0, 3, UPD>(acc, o, pdc, ptc, fr, fk, Seq13{});
-    if (J0 == 16) DF_CY(53);
-    __syncthreads();
-    if (J0 == 16) DF_CY(54);
 }
 
 template <int WK, bool HAS_T, bool TREE>
@@ -2008,6 +2203,10 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
                     mfma_tile<WK, I>(acc, o);
             }, Seq13{});
         }
+#ifdef VMM_STAMPS
+        if (m.stamp_j >= 0 && lane == 0 && it >= n_it - 8)
+            g_df_stamps[m.stamp_j][(WK == 0 ? 72 : 88) + (it - (n_it - 8))] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
     if (n_it > 0) {
         const double* XJ = m.Xs + ((n_it - 1) & 1) * 2 * kDfXs;
@@ -2040,9 +2239,11 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     Lds m;
     m.RA = smem;
     m.Pd = m.RA + 64 * kLdT;
-    m.Pt = m.Pd + 2 * 64 * kPs;
-    m.invd = m.Pt + 2 * 64 * kPs;
-    m.Xs = m.invd + 64;
+    m.Pt = m.Pd + 2 * 64 * kPsD;
+    m.invd = m.Pt + 2 * 64 * kPsD;
+    m.Pb = m.invd + 64;
+    m.Nd = m.Pb + 8 * kPsD;
+    m.Xs = m.Nd + 8 * kPsD;
     m.stamp_j = -1;
 #ifdef VMM_STAMPS
     if (HAS_T && R == j + 1)
