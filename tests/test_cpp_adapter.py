@@ -115,3 +115,28 @@ def test_incremental_pattern_through_the_patched_members():
     assert r.stdout.count("Solution ") == 2 * (len(cam_ids) + 2)
     assert r.stdout.count("Marker Position RMS =") == 2          # the final report of both runs (:781)
     print(line)
+
+
+@pytest.mark.gpu
+def test_incremental_pattern_timing_through_the_binding(capsys):
+    """incremental_test --time: the same call pattern at the size of bench.py --workload incremental (100 images x 60 tags,
+    visibility 0.3) with fixed initial poses -- no PnP, no Python: what the device path costs through the binding a
+    maintainer would use (DESIGN.md section 1 quotes the line).  Checked: both modes reconstruct the same scene and the
+    resident handle is not slower than a handle per call."""
+    _build()
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(2, n_cams=100, n_tags=60, visibility=0.3)
+    tag_ids = list(range(len(s.tag_init)))
+    cam_ids = list(range(len(s.cam_init)))
+    r = subprocess.run([EXE_INCR, "--time"], input=_scene_text(s, tag_ids, cam_ids), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    inc = next(l for l in r.stdout.splitlines() if l.startswith("INCREMENTAL")).split()
+    kv = dict(zip(inc[1:], inc[2:]))
+    assert kv["same_keys"] == "1" and float(kv["maxdiff"]) < 1e-9
+    line = next(l for l in r.stdout.splitlines() if l.startswith("TIMING"))
+    f = line.split()
+    t = dict(zip(f[1::2], f[2::2]))
+    assert int(t["bundle_adjustments"]) == len(cam_ids) + 2
+    assert float(t["resident_s"]) <= 1.05 * float(t["per_call_s"])
+    with capsys.disabled():
+        print("\n" + line)

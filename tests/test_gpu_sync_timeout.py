@@ -51,8 +51,18 @@ def _same(a, b, ca, ta, cb, tb):
 @pytest.mark.parametrize("once", ["0", "1"])
 @pytest.mark.parametrize("far", [False, True])
 def test_forced_spin_give_ups_keep_the_trajectory(monkeypatch, kernel, bit, once, far):
+    import os
     from visual_marker_mapping_amd import engine as eng
     from visual_marker_mapping_amd.synthetic import make_scene
+    # the suite is also run with one of the one-launch kernels switched off (VMM_BA_NO_DATAFLOW / VMM_BA_NO_CHAIN, DESIGN.md
+    # section 6): a kernel that does not run cannot give up
+    alive = {"df": os.environ.get("VMM_BA_NO_DATAFLOW") != "1", "chain": os.environ.get("VMM_BA_NO_CHAIN") != "1"}
+    if kernel == "both":
+        if not (alive["df"] or alive["chain"]):
+            pytest.skip("both one-launch kernels are switched off")
+        bit = 1 if alive["df"] else 2
+    elif not alive[kernel]:
+        pytest.skip("the %s kernel is switched off by the environment" % kernel)
     # 24 / 30 kept poses: reduced order 144 / 180 = 3 blocks, so both one-launch kernels have workgroups that wait
     s = make_scene(1, **FAR) if far else make_scene(5, n_cams=60, n_tags=30)
     robust = 0 if far else 1
@@ -110,3 +120,49 @@ def test_covariance_survives_a_give_up(monkeypatch):
     monkeypatch.setenv("VMM_BA_DEBUG_SPIN_LIMIT", "1")
     got = cov()
     np.testing.assert_allclose(got, ref, rtol=1e-7, atol=1e-20)
+
+
+def _two_clusters(s):
+    """The close-up scene cut into two walls that no image sees both of: tags [0, n/2) and [n/2, n); an image keeps
+    the observations of the half its first tag is in.  The co-observation graph of the tags then has (at least) two
+    components -- a tree ordering gets independent roots without a separator between them."""
+    import copy
+    n_tags = len(s.tag_init)
+    half = n_tags // 2
+    first = {}
+    for c, t in zip(s.obs_cam, s.obs_tag):
+        first.setdefault(int(c), int(t) >= half)
+    keep = np.array([(int(t) >= half) == first[int(c)] for c, t in zip(s.obs_cam, s.obs_tag)])
+    t = copy.copy(s)
+    t.obs_cam, t.obs_tag, t.obs_px = s.obs_cam[keep].copy(), s.obs_tag[keep].copy(), s.obs_px[keep].copy()
+    return t
+
+
+@pytest.mark.parametrize("order", ["nd", "natural"])
+def test_give_up_of_a_single_workgroup_is_reported(monkeypatch, order):
+    """ONE workgroup of the one-launch factorisation gives up (VMM_BA_DEBUG_SPIN_WG), the others only learn of it through
+    the abort word -- or not at all: with a tree ordering of two walls that share no image the last block column of the
+    factor does not depend on the other wall's columns, and until round 3 only that column's workgroup reported give-ups
+    (ADVICE round 3).  Whichever workgroup it is: the pass is redone and the trajectory is the undisturbed one."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = _two_clusters(make_scene(2, n_cams=300, n_tags=200, neighbors_min=6, neighbors_max=10))
+    monkeypatch.setenv("VMM_BA_ORDER", order)
+    monkeypatch.setenv("VMM_BA_SCHUR", "sparse")
+    ref, cam0, tag0, _ = _solve(s, 0, eng.ELIM_CAMERAS)
+    assert ref["num_sync_timeouts"] == 0
+    if order == "nd":
+        assert ref["tree_ordering"] >= 2
+    monkeypatch.setenv("VMM_BA_DEBUG_SPIN_LIMIT", "1")
+    monkeypatch.setenv("VMM_BA_DEBUG_SPIN_KERNEL", "df")
+    monkeypatch.setenv("VMM_BA_DEBUG_SPIN_ONCE", "1")
+    hit = 0
+    for wg in range(1, 280, 12):   # block columns early and late, leaves and separators, diagonal-only workgroups
+        monkeypatch.setenv("VMM_BA_DEBUG_SPIN_WG", str(wg))
+        out, cam, tag, again = _solve(s, 0, eng.ELIM_CAMERAS)
+        assert out["num_sync_timeouts"] in (0, 1)      # a workgroup without anything to wait for cannot give up
+        hit += out["num_sync_timeouts"]
+        if out["num_sync_timeouts"]:
+            assert out["sync_timeout_kernels"] & 1
+        _same(out, ref, cam, tag, cam0, tag0)
+    assert hit >= 4, "hardly any of the chosen workgroups had to wait: the test checks nothing"

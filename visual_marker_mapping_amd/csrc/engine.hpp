@@ -66,6 +66,7 @@ struct LmCtl {
     int32_t num_sync_timeouts; // passes of this solve redone on the fallback path
     int32_t sync_kernels;      // OR of sync_timeout over the solve
     uint32_t spin_limit_df, spin_limit_chain;   // 0 = the kernels' defaults (VMM_BA_DEBUG_SPIN_LIMIT shrinks them)
+    int32_t spin_wg;           // debugging: the shrunk limit applies to this workgroup (blockIdx.x) only; < 0: to all
     int32_t records;           // trace rows pushed (== Ceres summary.iterations.size())
     int32_t num_successful, num_unsuccessful, num_lm_iterations, num_jac_evals, num_cost_evals;
     int32_t trace_capacity;
@@ -213,6 +214,7 @@ struct Engine {
     // force spin give-ups in the one-launch factorisation / back-substitution (tests/test_gpu_edge_cases.py)
     uint32_t dbg_spin_df = 0, dbg_spin_chain = 0;
     bool dbg_spin_once = false;
+    int dbg_spin_wg = -1;           // VMM_BA_DEBUG_SPIN_WG=<blockIdx.x>: only that workgroup gives up
     double* yf = nullptr;           // [ldz] solution of the reduced system (scaled coordinates)
     double* step_comm = nullptr;    // [7*n_e + 1]: delta of the eliminated family | per-pose cross terms | votes
     double* cost_comm = nullptr;    // [2] candidate cost (all-reduced)

@@ -978,9 +978,10 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
                                                          unsigned* epoch_word, const double* __restrict__ Ld,
                                                          const double* __restrict__ Linv)
 {
-    // (a give-up inside the dataflow factorisation before this launch has set done = 2: a workgroup that stops
-    // waiting poisons and still publishes, so the factorisation's last workgroup ends after every give-up and sees
-    // the abort word)
+    // (a give-up inside the dataflow factorisation before this launch has set done = 2: every workgroup that stops
+    // waiting raises it itself, report_give_up)
+    // (the abort word itself is not looked at here: the epoch it is compared with is being retired by this very launch, and
+    // every workgroup of the factorisation that gave up has raised done = 2 itself before that kernel ended)
     if (ctl->done || ctl->lin_fail) {
         // the factorisation before this launch may have tagged granules with the current epoch: retire it even
         // when the solve is skipped (every workgroup of this launch leaves here, so nobody needs the old value)
@@ -988,7 +989,8 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(LmCtl* ctl, const doubl
             *epoch_word = *epoch_word + 1u;
         return;
     }
-    const unsigned spin_limit = ctl->spin_limit_chain ? ctl->spin_limit_chain : kSpinLimit;
+    const unsigned spin_limit = (ctl->spin_limit_chain && (ctl->spin_wg < 0 || ctl->spin_wg == (int)blockIdx.x))
+                                    ? ctl->spin_limit_chain : kSpinLimit;
     __shared__ double L[64 * kLd];    // L(m+1, m) for the product B_m
     __shared__ double Li[64 * kLd];   // Linv_m
     __shared__ double red[4][64];
@@ -1174,9 +1176,10 @@ __global__ __launch_bounds__(256) void k_backsolve_chain_tree(LmCtl* ctl, const 
                                                          const double* __restrict__ Linv,
                                                          const unsigned long long* __restrict__ nz, unsigned* n_done)
 {
-    // (a give-up inside the dataflow factorisation before this launch has set done = 2: a workgroup that stops
-    // waiting poisons and still publishes, so the factorisation's last workgroup ends after every give-up and sees
-    // the abort word)
+    // (a give-up inside the dataflow factorisation before this launch has set done = 2: every workgroup that stops
+    // waiting raises it itself, report_give_up)
+    // (the abort word itself is not looked at here: the epoch it is compared with is being retired by this very launch, and
+    // every workgroup of the factorisation that gave up has raised done = 2 itself before that kernel ended)
     if (ctl->done || ctl->lin_fail) {
         // the factorisation before this launch may have tagged granules with the current epoch: retire it even
         // when the solve is skipped (every workgroup of this launch leaves here, so nobody needs the old value)
@@ -1184,7 +1187,8 @@ __global__ __launch_bounds__(256) void k_backsolve_chain_tree(LmCtl* ctl, const 
             chain_block_done(n_done, n_blk, epoch_word, *epoch_word + 1u, nz != nullptr, n_blk - 1 - (int)blockIdx.x);
         return;
     }
-    const unsigned spin_limit = ctl->spin_limit_chain ? ctl->spin_limit_chain : kSpinLimit;
+    const unsigned spin_limit = (ctl->spin_limit_chain && (ctl->spin_wg < 0 || ctl->spin_wg == (int)blockIdx.x))
+                                    ? ctl->spin_limit_chain : kSpinLimit;
     __shared__ double L[64 * kLd];    // L(m+1, m) for the product B_m
     __shared__ double Li[64 * kLd];   // Linv_m
     __shared__ double red[4][64];
@@ -2224,6 +2228,18 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
     worker_round<WK, 56, HAS_T>(lane, acc, m);
 }
 
+// A give-up anywhere is a synchronisation failure, not an indefinite matrix: the pass pauses (LmCtl::done = 2) and the host
+// redoes the factorisation without the dataflow.  EVERY workgroup reports for itself -- the one that gave up, and any that
+// ends after somebody raised the abort word.  (Until round 3 only the last block column's workgroup did, on the grounds that
+// it ends after everybody else; with a tree ordering of a kept family whose co-observation graph is not connected that is
+// not true -- the last column depends on its own component only -- and a give-up in the other component went unreported.)
+__device__ __forceinline__ void report_give_up(const DfArgs& a, const unsigned epoch, const int& s_timeout)
+{
+    if (threadIdx.x == 0
+        && (s_timeout || __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch))
+        raise_sync_timeout(a.ctl, 1);
+}
+
 template <bool HAS_T, bool TREE>
 __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, double* smem)
 {
@@ -2289,6 +2305,7 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
         __syncthreads();
         if (j < n_blk - 1)   // the chain solves the last block directly
             chol_inverse_lds(Li, di, a.Linv + (int64_t)j * 4096);
+        report_give_up(a, epoch, s_timeout);
         return;
     }
     for (int idx = tid; idx < 64 * 32; idx += 256) {
@@ -2297,15 +2314,9 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
             *reinterpret_cast<double2*>(a.S + (int64_t)(R0 + rr) * ld + K0 + c)
                 = make_double2(m.RA[rr * kLd + c], m.RA[rr * kLd + c + 1]);
     }
-    if (j == n_blk - 1 && tid == 0) {
-        // a give-up anywhere (the result is NaN-poisoned then, so `ok` says nothing) is a synchronisation failure,
-        // not an indefinite matrix: the pass pauses and the host redoes the factorisation without the dataflow
-        const bool aborted = __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
-        if (s_timeout || aborted)
-            raise_sync_timeout(a.ctl, 1);
-        else if (!ok)
-            a.ctl->lin_fail = 1;
-    }
+    if (j == n_blk - 1 && tid == 0 && !ok)
+        a.ctl->lin_fail = 1;   // (with a give-up the result is NaN-poisoned and `ok` says nothing: the pass is redone anyway)
+    report_give_up(a, epoch, s_timeout);
 }
 
 } // namespace df2
@@ -2315,7 +2326,8 @@ __device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
 {
     if (a.ctl->done)
         return;
-    a.spin_limit = a.ctl->spin_limit_df ? a.ctl->spin_limit_df : kDfSpinDefault;
+    a.spin_limit = (a.ctl->spin_limit_df && (a.ctl->spin_wg < 0 || a.ctl->spin_wg == (int)blockIdx.x)) ? a.ctl->spin_limit_df
+                                                                                                          : kDfSpinDefault;
     phase_stamp(a.ctl, 3);
     if (a.ctl->lin_fail)
         return;

@@ -122,9 +122,11 @@ static Rccl& rccl()
     return r;
 }
 
-// VMM_BA_DEBUG_SPIN_LIMIT=<polls> [VMM_BA_DEBUG_SPIN_KERNEL=df|chain|both] [VMM_BA_DEBUG_SPIN_ONCE=1]: shrink the bounded
-// spins of k_chol_dataflow / k_backsolve_chain so that they give up (tests of the recovery path only).  A limit of 1
-// makes every wait give up at its first poll, arrived data or not: every pass is then redone, deterministically.
+// VMM_BA_DEBUG_SPIN_LIMIT=<polls> [VMM_BA_DEBUG_SPIN_KERNEL=df|chain|both] [VMM_BA_DEBUG_SPIN_ONCE=1] [VMM_BA_DEBUG_SPIN_WG=<b>]:
+// shrink the bounded spins of k_chol_dataflow / k_backsolve_chain so that they give up (tests of the recovery path only).
+// A limit of 1 makes every wait give up at its first poll, arrived data or not: every pass is then redone,
+// deterministically.  With _WG only workgroup b of the launch gets the shrunk limit -- a give-up that the other workgroups
+// learn of through the abort word only (or not at all, when their part of the factor does not depend on b's).
 static void read_spin_debug_env(Engine& e)
 {
     const char* sl = getenv("VMM_BA_DEBUG_SPIN_LIMIT");
@@ -139,6 +141,8 @@ static void read_spin_debug_env(Engine& e)
         e.dbg_spin_chain = lim;
     const char* so = getenv("VMM_BA_DEBUG_SPIN_ONCE");
     e.dbg_spin_once = so && so[0] == '1';
+    const char* sw = getenv("VMM_BA_DEBUG_SPIN_WG");
+    e.dbg_spin_wg = sw ? atoi(sw) : -1;
 }
 
 // Sorts the observations by one pose family (stable counting sort) and cuts each pose's run into
@@ -830,6 +834,7 @@ static void init_ctl(Engine& e, LmCtl& c, const vmm_ba_options& o, int trace_cap
     memset(&c, 0, sizeof(c));
     c.spin_limit_df = e.dbg_spin_df;
     c.spin_limit_chain = e.dbg_spin_chain;
+    c.spin_wg = e.dbg_spin_wg;
     c.max_num_iterations = o.max_num_iterations;
     c.robustify = o.robustify;
     c.jacobi_scaling = o.jacobi_scaling;
@@ -1303,12 +1308,22 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         const double dense_flops = (double)(e.n_pad + 1) * (e.n_pad + 2) * e.k_dim;
         const double sparse_flops = 432.0 * pairs + 72.0 * (double)e.n_obs;
         const double dense_us = dense_flops / 44e6 + 12.0, sparse_us = sparse_flops / 9e6 + 18.0;
-        e.sparse_schur = e.n_obs > 0 && sparse_us < dense_us;
+        // The plan of the block-sparse form lists every term: one (left, right) position pair per product plus the
+        // right-hand-side term of every observation -- known from the degrees alone, before anything is allocated.  16 bytes
+        // per term on the host while it is built, 8 on the device: the automatic choice stays below 4e7 terms (0.64 GB
+        // transient, 0.32 GB resident; 2000 x 1000 at 25 % visibility would be 6e7), a forced one below the 2^31 the
+        // 32-bit positions can address.
+        const double plan_terms = pairs + (double)e.n_obs;
+        e.sparse_schur = e.n_obs > 0 && sparse_us < dense_us && plan_terms <= 4e7;
         if (const char* sv = getenv("VMM_BA_SCHUR")) {
             if (!strcmp(sv, "dense"))
                 e.sparse_schur = false;
             else if (!strcmp(sv, "sparse"))
                 e.sparse_schur = e.n_obs > 0;
+        }
+        if (e.sparse_schur && plan_terms >= 2147483647.0) {
+            set_error("block-sparse elimination: more than 2^31 block products (set VMM_BA_SCHUR=dense)");
+            return fail(VMM_BA_ERR_ARGUMENT);
         }
         e.schur_flops = e.sparse_schur ? sparse_flops : dense_flops;
     }
@@ -1353,7 +1368,10 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
             // Worth it?  The factorisation is a chain of dependent block columns (~11 us each): the longest chain under
             // the tree ordering (block structure after symbolic fill, nodes as dense blocks: an upper bound) against the
             // n_blk of the natural order.  Taken when it is at most 0.7 of it (VMM_BA_ORDER=nd: always).
-            bool take = nodes.size() > 2 && dataflow_workgroups(n_pad_nd / kNB) <= dataflow_max_workgroups(e.n_cu);
+            // (the block structure is kept as one 64-bit mask per block row and chol_order as [n_blk][64]: 64 block columns
+            // at most, whatever VMM_BA_DF_MAX_WG or the number of compute units would allow)
+            bool take = nodes.size() > 2 && n_pad_nd / kNB <= 64
+                        && dataflow_workgroups(n_pad_nd / kNB) <= dataflow_max_workgroups(e.n_cu);
             if (take && !forced) {
                 const int nb = n_pad_nd / kNB;
                 std::vector<unsigned long long> nzr((size_t)nb, 0ull);
@@ -2360,6 +2378,7 @@ int vmm_ba_dense_spd_solve(int device, int n, const double* A, const double* b, 
         if (attempt == 0) {
             c.spin_limit_df = e.dbg_spin_df;
             c.spin_limit_chain = e.dbg_spin_chain;
+            c.spin_wg = e.dbg_spin_wg;
         }
         err = hipMemcpyAsync(e.ctl, &c, sizeof(LmCtl), hipMemcpyHostToDevice, e.stream);
         if (err == hipSuccess)
