@@ -96,6 +96,62 @@ def test_f32_accumulate_mid_size_matches_oracle(oracle):
     assert abs(out["final_cost"] - exp) < 0.02 * exp
 
 
+_CONFIG4_FIRST = {}
+
+
+def _config4_first_iteration(oracle, s):
+    """The oracle's first LM iteration on configs[3] (Schur path, 8 threads): computed once per session."""
+    if not _CONFIG4_FIRST:
+        sc = oracle.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+        summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, num_threads=8, max_num_iterations=1))
+        _CONFIG4_FIRST.update(sc=sc, summ=summ, trace=trace)
+    return _CONFIG4_FIRST
+
+
+def _assert_first_iteration(eng, ba, one, first):
+    summ, trace, sc = first["summ"], first["trace"], first["sc"]
+    assert one["iterations"] == summ["iterations"] == 2 and one["termination_type"] == eng.NO_CONVERGENCE
+    np.testing.assert_allclose(one["trace"][0]["cost"], trace[0]["cost"], rtol=1e-12)
+    np.testing.assert_allclose(one["trace"][0]["gradient_max_norm"], trace[0]["gradient_max_norm"], rtol=1e-9)
+    assert one["trace"][1]["step_is_successful"] == trace[1]["step_is_successful"] == 1
+    np.testing.assert_allclose(one["trace"][1]["cost"], trace[1]["cost"], rtol=1e-4)
+    np.testing.assert_allclose(one["trace"][1]["model_cost_change"], trace[1]["model_cost_change"], rtol=1e-5)
+    np.testing.assert_allclose(one["trace"][1]["step_norm"], trace[1]["step_norm"], rtol=1e-5)
+    np.testing.assert_allclose(one["trace"][1]["trust_region_radius"], trace[1]["trust_region_radius"], rtol=1e-4)
+    cam1, tag1 = ba.get_state()
+    scale = max(np.abs(sc.cam_qt).max(), np.abs(sc.tag_qt).max())
+    np.testing.assert_allclose(cam1, sc.cam_qt, rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(tag1, sc.tag_qt, rtol=0, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("recover", [False, True])
+def test_config4_first_iteration_block_sparse_elimination(oracle, monkeypatch, recover):
+    """2000 x 1000 with the block-sparse elimination forced (VMM_BA_SCHUR=sparse: 1.0e9 pair terms, an 8 GB term list on the
+    device, the reduced system of 94 block columns on the launch-per-column factorisation with the one-launch kernel on
+    the last 34): the first LM iteration against the oracle.  Round 3 saw this configuration 0.29 % off once
+    (gpurun_out/r3z/tests_all_nd.txt) and green minutes later without a recorded cause -- DESIGN.md section 4.11; this is
+    its permanent test.  recover: the same with the one-launch kernels of the tail forced to give up, i.e. the pass
+    redone from the rank-k update on (S is rebuilt by k_fill_lower + k_schur_pairs) -- the path that runs when the 629
+    workgroups of the tail are not dispatched in order."""
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(4)
+    first = _config4_first_iteration(oracle, s)
+    monkeypatch.setenv("VMM_BA_SCHUR", "sparse")
+    if recover:
+        monkeypatch.setenv("VMM_BA_DEBUG_SPIN_LIMIT", "1")
+        monkeypatch.setenv("VMM_BA_DEBUG_SPIN_KERNEL", "both")
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px,
+                            precision=eng.PRECISION_F32_ACCUM)
+    try:
+        one = ba.solve(eng.default_options(robustify=0, max_num_iterations=1), trace_capacity=8)
+        assert one["block_sparse"] == 1
+        assert (one["num_sync_timeouts"] >= 1) == recover, one["num_sync_timeouts"]
+        _assert_first_iteration(eng, ba, one, first)
+    finally:
+        ba.close()
+
+
 def test_config4_full_size_f32_accumulate(oracle):
     """BASELINE.json configs[3]: 2000 images x 1000 tags (2 000 000 tag observations, reduced system of order
     6000), f32 J^T J accumulation.  Checked at full size: (i) the evaluation kernels against the oracle's
@@ -151,19 +207,8 @@ def test_config4_full_size_f32_accumulate(oracle):
                                    rtol=1e-12)
         # (ii) one LM iteration against the oracle
         one = ba.solve(eng.default_options(robustify=0, max_num_iterations=1), trace_capacity=8)
-        summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, num_threads=8, max_num_iterations=1))
-        assert one["iterations"] == summ["iterations"] == 2 and one["termination_type"] == eng.NO_CONVERGENCE
-        np.testing.assert_allclose(one["trace"][0]["cost"], trace[0]["cost"], rtol=1e-12)
-        np.testing.assert_allclose(one["trace"][0]["gradient_max_norm"], trace[0]["gradient_max_norm"], rtol=1e-9)
-        assert one["trace"][1]["step_is_successful"] == trace[1]["step_is_successful"] == 1
-        np.testing.assert_allclose(one["trace"][1]["cost"], trace[1]["cost"], rtol=1e-4)
-        np.testing.assert_allclose(one["trace"][1]["model_cost_change"], trace[1]["model_cost_change"], rtol=1e-5)
-        np.testing.assert_allclose(one["trace"][1]["step_norm"], trace[1]["step_norm"], rtol=1e-5)
-        np.testing.assert_allclose(one["trace"][1]["trust_region_radius"], trace[1]["trust_region_radius"], rtol=1e-4)
-        cam1, tag1 = ba.get_state()
-        scale = max(np.abs(sc.cam_qt).max(), np.abs(sc.tag_qt).max())
-        np.testing.assert_allclose(cam1, sc.cam_qt, rtol=0, atol=1e-5 * scale)
-        np.testing.assert_allclose(tag1, sc.tag_qt, rtol=0, atol=1e-5 * scale)
+        first = _config4_first_iteration(oracle, s)
+        _assert_first_iteration(eng, ba, one, first)
         # (iii) the whole solve from the initial state
         ba.set_state(s.cam_init, s.tag_init)
         out = ba.solve(eng.default_options(robustify=0), trace_capacity=64)

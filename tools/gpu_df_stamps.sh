@@ -24,11 +24,7 @@ for rep in range(3):
         print("j=%2d start %7.2f [slice 6 seen %7.2f slice 7 seen %7.2f] consumed %7.2f rounds %s" % (j, r[0], d[0], d[1], r[1], " ".join("%7.2f" % v for v in r[2:10])))
     for j in (5, 6):
         print("j=%d: slices of panel %d published at %s" % (j, j - 1, " ".join("%7.2f" % v for v in (s[j - 1, 2:10] - t0) / 100.0)))
-        print("      seen by workgroup (%d, %d) at      %s" % (j, j + 1, " ".join("%7.2f" % v for v in (s[j, 14:22] - t0) / 100.0)))
-        print("      its wave 1 (rows %d) saw its slice at %s" % (j + 1, " ".join("%7.2f" % v for v in (s[j, 64:72] - t0) / 100.0)))
-        print("      barrier behind the staging passed at %s" % " ".join("%7.2f" % v for v in (s[j, 80:88] - t0) / 100.0))
-        print("      worker 0 issued its MFMAs of it at   %s" % " ".join("%7.2f" % v for v in (s[j, 72:80] - t0) / 100.0))
-        print("      worker 1                             %s" % " ".join("%7.2f" % v for v in (s[j, 88:96] - t0) / 100.0))
+        print("      seen by workgroup (%d, %d) at         %s (even: its worker wave 0, odd: its pivot wave 0)" % (j, j + 1, " ".join("%7.2f" % v for v in (s[j, 14:22] - t0) / 100.0)))
     j = 5
     p = s[j, 40:45] - s[j, 40]
     wk = s[j, 48:53] - s[j, 48]

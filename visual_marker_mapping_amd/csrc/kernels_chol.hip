@@ -2262,7 +2262,7 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     m.Xs = m.Nd + 8 * kPsD;
     m.stamp_j = -1;
 #ifdef VMM_STAMPS
-    if (HAS_T && R == j + 1)
+    if (TREE ? !HAS_T : (HAS_T && R == j + 1))   // tree orderings: the diagonal-only workgroup (block (j+1, j) may be empty)
         m.stamp_j = j;
     {
         const bool stamp_on = m.stamp_j >= 0 && w == 0;
