@@ -172,7 +172,10 @@ def main():
     ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam[idx],
                             s.obs_tag[idx], s.obs_px[idx], device=local_rank, elimination=elim, rank=rank,
                             world_size=world,
-                            precision=eng.PRECISION_F32_ACCUM if precision == "f32" else eng.PRECISION_F64)
+                            precision=eng.PRECISION_F32_ACCUM if precision == "f32" else eng.PRECISION_F64,
+                            # every rank generates the whole scene: the structure of all ranks' observations lets them
+                            # order the kept family alike (tree ordering on close-up scenes; no effect at visibility 1.0)
+                            structure_obs=(s.obs_cam, s.obs_tag) if world > 1 else None)
     setup_s = time.time() - t0
     collective_used = None
     if use_dist:
@@ -195,7 +198,8 @@ def main():
                     ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag,
                                             s.obs_cam[idx], s.obs_tag[idx], s.obs_px[idx], device=local_rank,
                                             elimination=elim, rank=rank, world_size=world,
-                                            precision=eng.PRECISION_F32_ACCUM if precision == "f32" else eng.PRECISION_F64)
+                                            precision=eng.PRECISION_F32_ACCUM if precision == "f32" else eng.PRECISION_F64,
+                                            structure_obs=(s.obs_cam, s.obs_tag))
                 ba.set_allreduce(vdist.make_allreduce(local_rank))
                 collective_used = "callback (native RCCL set-up failed%s)" % (": %s" % err if err is not None else " on another rank")
         else:

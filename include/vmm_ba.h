@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VMM_BA_ABI_VERSION 3
+#define VMM_BA_ABI_VERSION 4
 
 typedef struct vmm_ba_handle_s* vmm_ba_handle;
 
@@ -99,6 +99,14 @@ typedef struct vmm_ba_create_options {
      * (zero gradient) is unchanged, the LM trajectory is that of a slightly perturbed Gauss-Newton model. */
     int32_t precision;
     int32_t landmarks;       /* VMM_BA_LANDMARK_* */
+    /* world_size > 1 only, optional (ABI 4): the (camera, tag) index pairs of the observations of ALL ranks -- the same
+     * arrays on every rank, structure only, no pixels; the caller keeps them alive during vmm_ba_create only.  The
+     * reduced systems of the ranks are summed and must share one layout: with the global structure every rank orders the
+     * kept family by the same nested dissection (tree ordering, vmm_ba_summary.tree_ordering); without it world_size > 1
+     * keeps the natural order.  The reference is a single process (src/TagReconstructor.cpp:646-743): no counterpart. */
+    int64_t n_structure_obs;
+    const int32_t* structure_obs_cam;
+    const int32_t* structure_obs_tag;
 } vmm_ba_create_options;
 
 /* Solver::Options fields the reference sets (src/TagReconstructor.cpp:725-735) plus the Ceres

@@ -327,3 +327,62 @@ def test_bench_harness_two_ranks_gloo():
     assert d["collective"].startswith("callback")
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-9
     assert "500 images x 200 tags" in d["config"]["workload"]
+
+
+def _tree_worker(rank, world, port, out, with_structure):
+    import torch
+    import torch.distributed as dist
+    from visual_marker_mapping_amd import distributed as vd
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    s = make_scene(2, neighbors_min=6, neighbors_max=10)
+    idx, elim_cams = vd.shard_observations(s.obs_cam, s.obs_tag, len(s.cam_init), len(s.tag_init), rank, world, None)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam[idx],
+                            s.obs_tag[idx], s.obs_px[idx], device=0, rank=rank, world_size=world,
+                            structure_obs=(s.obs_cam, s.obs_tag) if with_structure else None)
+    ba.set_allreduce(vd.make_allreduce(0))
+    o = ba.solve(eng.default_options(robustify=0), trace_capacity=64)
+    cam, tag = ba.get_state()
+    ba.close()
+    np.savez(out % rank, cam=cam, tag=tag, iters=o["iterations"], final=o["final_cost"], term=o["termination_type"],
+             costs=[t["cost"] for t in o["trace"]], ok=[t["step_is_successful"] for t in o["trace"]],
+             tree=o["tree_ordering"], sparse=o["block_sparse"], n_sync=o["num_sync_timeouts"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_structure", [True, False])
+def test_two_ranks_tree_ordering_of_the_close_up_scene(tmp_path, with_structure):
+    """World > 1 on a realistic scene (500 images x 200 tags, every image sees its 6..10 nearest tags).  The ranks' reduced
+    systems are summed, so they must share ONE layout: with the structure of all ranks' observations
+    (vmm_ba_create_options.structure_obs_*) every rank makes the same nested dissection of the kept family and the
+    tree-ordered one-launch factorisation runs on the summed system (round 3: world > 1 always kept the natural order);
+    without it the ranks stay with the natural order.  Either way: the 1-rank trajectory (the reference's single process,
+    src/TagReconstructor.cpp:646-743) and bit-identical ranks."""
+    mp = pytest.importorskip("torch.multiprocessing")
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(2, neighbors_min=6, neighbors_max=10)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+    ref = ba.solve(eng.default_options(robustify=0), trace_capacity=64)
+    cam0, tag0 = ba.get_state()
+    ba.close()
+    assert ref["tree_ordering"] >= 3
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_tree_worker, args=(2, _free_port(), out, with_structure), nprocs=2, join=True)
+    r = [np.load(out % k) for k in range(2)]
+    for k in ("cam", "tag", "costs", "ok", "iters", "final", "term", "tree", "sparse"):
+        np.testing.assert_array_equal(r[1][k], r[0][k])
+    r0 = r[0]
+    assert int(r0["n_sync"]) == 0 and int(r0["term"]) == eng.CONVERGENCE
+    if with_structure:
+        assert int(r0["tree"]) == ref["tree_ordering"] and int(r0["sparse"]) == 1
+    else:
+        assert int(r0["tree"]) == 0
+    assert int(r0["iters"]) == ref["iterations"]
+    np.testing.assert_array_equal(r0["ok"], [t["step_is_successful"] for t in ref["trace"]])
+    np.testing.assert_allclose(r0["costs"], [t["cost"] for t in ref["trace"]], rtol=1e-9)
+    np.testing.assert_allclose(r0["cam"], cam0, rtol=0, atol=1e-9 * np.abs(cam0).max())
+    np.testing.assert_allclose(r0["tag"], tag0, rtol=0, atol=1e-9 * np.abs(tag0).max())

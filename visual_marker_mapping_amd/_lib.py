@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VMM_BA_LIB selects another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("VMM_BA_LIB") or os.path.join(_HERE, "libvmm_ba.so")
 
-ABI_VERSION = 3          # VMM_BA_ABI_VERSION of include/vmm_ba.h
+ABI_VERSION = 4          # VMM_BA_ABI_VERSION of include/vmm_ba.h
 RCCL_ID_BYTES = 128      # VMM_BA_RCCL_ID_BYTES
 PRECISION_F64, PRECISION_F32_ACCUM = 0, 1
 LANDMARK_TAG_POSES, LANDMARK_POINTS = 0, 1
@@ -38,7 +38,9 @@ class Problem(C.Structure):
 
 class CreateOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("elimination", C.c_int32), ("rank", C.c_int32),
-                ("world_size", C.c_int32), ("precision", C.c_int32), ("landmarks", C.c_int32)]
+                ("world_size", C.c_int32), ("precision", C.c_int32), ("landmarks", C.c_int32),
+                ("n_structure_obs", C.c_int64), ("structure_obs_cam", C.POINTER(C.c_int32)),
+                ("structure_obs_tag", C.POINTER(C.c_int32))]
 
 
 class Options(C.Structure):

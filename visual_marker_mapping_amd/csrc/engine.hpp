@@ -190,6 +190,7 @@ struct Engine {
     bool explicit_pairs = false;    // only the pairs that share an eliminated pose are listed (pair_col), S zero-filled first
     int32_t* pair_col = nullptr;    // [n_pairs] first column of the pair's block in S (-1: the row's right-hand side entry)
     int32_t* row_of = nullptr;      // [n_f] first row of every kept pose in the reduced system (explicit form only)
+    int32_t* pose_of_row = nullptr; // [n_pad] world > 1 with a tree ordering: kept pose of a row of the reduced system, -1: padding
     std::vector<int32_t> h_row_of;  // host copy; empty: kept pose f sits at row 6 f
     unsigned long long* chol_nz = nullptr;    // [n_blk + 1] block structure of the factor (tree ordering), see DfArgs::nz
     unsigned char* chol_order = nullptr;      // [n_blk][64] panel order per block column, see DfArgs::order

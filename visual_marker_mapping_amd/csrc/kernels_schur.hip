@@ -775,7 +775,8 @@ __global__ __launch_bounds__(256) void k_unpack_diag(const LmCtl* ctl, const dou
                                                      int f_off_pose, const double* __restrict__ H_F,
                                                      const double* __restrict__ g_F, const double* __restrict__ scale,
                                                      const double* __restrict__ D2, double* __restrict__ S, int n_red,
-                                                     int n_pad)
+                                                     int n_pad, const int32_t* __restrict__ pose_of_row,
+                                                     const int32_t* __restrict__ row_of)
 {
     if (ctl && ctl->done)
         return;
@@ -783,6 +784,32 @@ __global__ __launch_bounds__(256) void k_unpack_diag(const LmCtl* ctl, const dou
     const int64_t base = (int64_t)r * (r + 1) / 2;
     const double* sF = scale + 6 * (int64_t)f_off_pose;
     const double* dF = D2 + 6 * (int64_t)f_off_pose;
+    if (pose_of_row) {
+        // tree ordering of the kept family: pose f's rows are row_of[f] .. + 5, every other row is padding
+        const int fr = r < n_pad ? pose_of_row[r] : -1;
+        for (int c = threadIdx.x; c <= r; c += 256) {
+            double v = packed[base + c];
+            const int fc = c < n_pad ? pose_of_row[c] : -1;
+            if (r == n_pad) {
+                if (fc >= 0) {
+                    const int k = 6 * fc + (c - row_of[fc]);
+                    v += sF[k] * g_F[k];
+                }
+            } else if (fr >= 0) {
+                if (fc == fr) {
+                    const int a = r - row_of[fr], b = c - row_of[fr];
+                    double add = sF[6 * fr + a] * H_F[36 * (int64_t)fr + 6 * a + b] * sF[6 * fr + b];
+                    if (c == r)
+                        add += dF[6 * fr + a];
+                    v += add;
+                }
+            } else if (c == r) {
+                v = 1.0;
+            }
+            S[(int64_t)r * ld + c] = v;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c <= r; c += 256) {
         double v = packed[base + c];
         if (r == n_pad) {
@@ -819,7 +846,7 @@ void launch_pack_lower(Engine& e, bool unpack)
     const double* g_F = e.elim_cams ? e.g_tag : e.g_cam;
     hipLaunchKernelGGL(k_unpack_diag, dim3(e.n_pad + 1), dim3(256), 0, e.stream, (const LmCtl*)e.ctl,
                        (const double*)e.S_packed, e.ldz, f_off, H_F, g_F, (const double*)e.scale, (const double*)e.D2,
-                       e.S, e.n_red, e.n_pad);
+                       e.S, e.n_red, e.n_pad, (const int32_t*)e.pose_of_row, (const int32_t*)e.row_of);
 }
 
 

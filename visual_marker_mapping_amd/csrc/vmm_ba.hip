@@ -1297,29 +1297,64 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     // partial-tile sum take 118 us whatever the fill = 44 TFLOP/s; k_schur_pairs 16 us at 6-10 tags per image, 57 us at
     // 25 % and 116 us at 50 % visibility, priced as 18 us + 9 TFLOP/s of useful 6x6x6 block products);
     // VMM_BA_SCHUR=dense|sparse overrides.
+    // World > 1: every decision that shapes the reduced system (its form is free per rank, its LAYOUT is not: the ranks'
+    // systems are summed) is taken from the structure of ALL ranks' observations when the caller passes it
+    // (vmm_ba_create_options.structure_obs_*), else from this rank's own -- and then the layout stays the natural one.
+    // gStart / gOther: per eliminated pose the kept poses it sees (family-local indices), this rank's or everybody's.
+    std::vector<int32_t> gStartV, gOtherV;
+    const bool have_structure = co.n_structure_obs > 0 && co.structure_obs_cam && co.structure_obs_tag;
+    if (e.multi && have_structure) {
+        gStartV.assign((size_t)e.n_e + 1, 0);
+        for (int64_t d = 0; d < co.n_structure_obs; ++d) {
+            const int32_t c = co.structure_obs_cam[d], t = co.structure_obs_tag[d];
+            if (c < 0 || c >= p->n_cams || t < 0 || t >= p->n_tags) {
+                set_error("structure_obs index out of range");
+                return fail(VMM_BA_ERR_ARGUMENT);
+            }
+            if (e.points) {
+                set_error("structure_obs is not supported with point landmarks");
+                return fail(VMM_BA_ERR_ARGUMENT);
+            }
+            gStartV[(size_t)(e.elim_cams ? c : t) + 1]++;
+        }
+        for (int q = 0; q < e.n_e; ++q)
+            gStartV[(size_t)q + 1] += gStartV[(size_t)q];
+        gOtherV.resize((size_t)co.n_structure_obs);
+        std::vector<int32_t> fillg(gStartV.begin(), gStartV.end() - 1);
+        for (int64_t d = 0; d < co.n_structure_obs; ++d) {
+            const int32_t c = co.structure_obs_cam[d], t = co.structure_obs_tag[d];
+            gOtherV[(size_t)fillg[(size_t)(e.elim_cams ? c : t)]++] = e.elim_cams ? t : c;
+        }
+    }
+    const bool global_lists = !gStartV.empty();
+    const std::vector<int32_t>& gStart = global_lists ? gStartV : startE;
+    const std::vector<int32_t>& gOther = global_lists ? gOtherV : otherE;
+    // one layout for all ranks: this rank alone (also the one-rank test hook), or everybody's structure in hand
+    const bool layout_free = !e.multi || e.world == 1 || global_lists;
     {
         double pairs = 0.0;   // 6x6 block products of the lower triangle: sum over e of deg (deg + 1) / 2
         e.co_terms = 0.0;
         for (int q = 0; q < e.n_e; ++q) {
-            const double deg = (double)(startE[q + 1] - startE[q]);
+            const double deg = (double)(gStart[q + 1] - gStart[q]);
             pairs += 0.5 * deg * (deg + 1.0);
             e.co_terms += deg * deg;   // entries the host's adjacency lists of the kept family would hold before merging
         }
         const double dense_flops = (double)(e.n_pad + 1) * (e.n_pad + 2) * e.k_dim;
-        const double sparse_flops = 432.0 * pairs + 72.0 * (double)e.n_obs;
+        const double n_obs_model = global_lists ? (double)co.n_structure_obs : (double)e.n_obs;
+        const double sparse_flops = 432.0 * pairs + 72.0 * n_obs_model;
         const double dense_us = dense_flops / 44e6 + 12.0, sparse_us = sparse_flops / 9e6 + 18.0;
         // The plan of the block-sparse form lists every term: one (left, right) position pair per product plus the
         // right-hand-side term of every observation -- known from the degrees alone, before anything is allocated.  16 bytes
         // per term on the host while it is built, 8 on the device: the automatic choice stays below 4e7 terms (0.64 GB
         // transient, 0.32 GB resident; 2000 x 1000 at 25 % visibility would be 6e7), a forced one below the 2^31 the
         // 32-bit positions can address.
-        const double plan_terms = pairs + (double)e.n_obs;
-        e.sparse_schur = e.n_obs > 0 && sparse_us < dense_us && plan_terms <= 4e7;
+        const double plan_terms = pairs + n_obs_model;
+        e.sparse_schur = n_obs_model > 0 && sparse_us < dense_us && plan_terms <= 4e7;
         if (const char* sv = getenv("VMM_BA_SCHUR")) {
             if (!strcmp(sv, "dense"))
                 e.sparse_schur = false;
             else if (!strcmp(sv, "sparse"))
-                e.sparse_schur = e.n_obs > 0;
+                e.sparse_schur = n_obs_model > 0;
         }
         if (e.sparse_schur && plan_terms >= 2147483647.0) {
             set_error("block-sparse elimination: more than 2^31 block products (set VMM_BA_SCHUR=dense)");
@@ -1327,7 +1362,8 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         }
         e.schur_flops = e.sparse_schur ? sparse_flops : dense_flops;
     }
-    // Tree ordering of the kept family (VMM_BA_ORDER=nd; one GPU, block-sparse path): every node of the dissection tree
+    std::vector<std::vector<int32_t>> tree_nbr;   // co-observation graph of the kept family (all ranks' when known)
+    // Tree ordering of the kept family (VMM_BA_ORDER=nd; block-sparse path; world > 1: with the global structure): every node of the dissection tree
     // starts on a 64-row boundary of the reduced system (padding rows with a unit diagonal in between), so that whole
     // block columns of the factor belong to one node and the block columns of two parts of one level are independent.
     {
@@ -1335,13 +1371,14 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         const bool forced = ov && !strcmp(ov, "nd"), forbidden = ov && !strcmp(ov, "natural");
         // (the host-side graph work is bounded: 5e7 list entries, and a natural order beyond the one-launch kernel's 48 block
         // columns cannot become a tree order within them)
-        if (e.sparse_schur && !e.multi && !forbidden && e.n_f > 1 && e.n_blk >= 4 && e.n_blk <= 48 && e.co_terms <= 5e7) {
-            std::vector<std::vector<int32_t>> nbr((size_t)e.n_f);
+        if (e.sparse_schur && layout_free && !forbidden && e.n_f > 1 && e.n_blk >= 4 && e.n_blk <= 48 && e.co_terms <= 5e7) {
+            std::vector<std::vector<int32_t>>& nbr = tree_nbr;
+            nbr.assign((size_t)e.n_f, {});
             for (int q = 0; q < e.n_e; ++q)
-                for (int32_t d1 = startE[q]; d1 < startE[q + 1]; ++d1)
-                    for (int32_t d2 = startE[q]; d2 < startE[q + 1]; ++d2)
+                for (int32_t d1 = gStart[q]; d1 < gStart[q + 1]; ++d1)
+                    for (int32_t d2 = gStart[q]; d2 < gStart[q + 1]; ++d2)
                         if (d1 != d2)
-                            nbr[(size_t)otherE[(size_t)d1]].push_back(otherE[(size_t)d2]);
+                            nbr[(size_t)gOther[(size_t)d1]].push_back(gOther[(size_t)d2]);
             for (auto& v : nbr) {
                 std::sort(v.begin(), v.end());
                 v.erase(std::unique(v.begin(), v.end()), v.end());
@@ -1613,13 +1650,18 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
             std::vector<unsigned long long> nzr((size_t)e.n_blk + 1, 0ull);
             for (int i = 0; i < e.n_blk; ++i)
                 nzr[(size_t)i] |= 1ull << i;
-            for (int fq = 0; fq < e.n_f; ++fq)
-                for (const int32_t f2 : partners[(size_t)fq]) {
+            // (the co-observation graph the ordering was made from -- all ranks' with world > 1: the summed system has an
+            // entry wherever ANY rank has one -- plus every pose's own block)
+            for (int fq = 0; fq < e.n_f; ++fq) {
+                std::vector<int32_t> with_self(tree_nbr[(size_t)fq]);
+                with_self.push_back(fq);
+                for (const int32_t f2 : with_self) {
                     const int r1 = e.h_row_of[(size_t)fq], r2 = e.h_row_of[(size_t)f2];
                     for (int bi = r1 / kNB; bi <= (r1 + 5) / kNB; ++bi)
                         for (int bj = r2 / kNB; bj <= (r2 + 5) / kNB; ++bj)
                             nzr[(size_t)std::max(bi, bj)] |= 1ull << std::min(bi, bj);
                 }
+            }
             for (int k = 0; k < e.n_blk; ++k)
                 for (int i = k + 1; i < e.n_blk; ++i)
                     if ((nzr[(size_t)i] >> k) & 1ull)
@@ -1678,6 +1720,16 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
             if ((rc = dev_alloc(e, &e.row_of, rows.size()))) return fail(rc);
             if ((rc = upload(e, e.pair_col, pcol))) return fail(rc);
             if ((rc = upload(e, e.row_of, rows))) return fail(rc);
+            if (e.multi && !e.h_row_of.empty()) {
+                // world > 1 with a tree ordering: which kept pose a row of the reduced system belongs to (-1: padding), for the
+                // kernel that adds the kept family's diagonal blocks behind the all-reduce (k_unpack_diag)
+                std::vector<int32_t> pose_of((size_t)e.n_pad, -1);
+                for (int fq = 0; fq < e.n_f; ++fq)
+                    for (int k = 0; k < 6; ++k)
+                        pose_of[(size_t)rows[(size_t)fq] + k] = fq;
+                if ((rc = dev_alloc(e, &e.pose_of_row, pose_of.size()))) return fail(rc);
+                if ((rc = upload(e, e.pose_of_row, pose_of))) return fail(rc);
+            }
         }
         if (hipStreamSynchronize(e.stream) != hipSuccess) {   // host vectors go out of scope
             set_error("create: upload of the block-sparse plan failed");

@@ -29,7 +29,7 @@ def default_options(**kw):
 class BundleAdjuster:
     def __init__(self, intr, dist, cam_qt, tag_qt, tag_wh, fixed_tag, obs_cam, obs_tag, obs_px,
                  device=0, elimination=ELIM_AUTO, rank=0, world_size=1, precision=PRECISION_F64,
-                 landmarks=LANDMARK_TAG_POSES):
+                 landmarks=LANDMARK_TAG_POSES, structure_obs=None):
         L = _lib.lib()
         self._h = C.c_void_p()
         self.intr = np.ascontiguousarray(intr, np.float64).reshape(4)
@@ -60,6 +60,14 @@ class BundleAdjuster:
         co.precision = int(precision)
         co.landmarks = int(landmarks)
         self.landmarks = int(landmarks)
+        if structure_obs is not None:
+            # world_size > 1: the (camera, tag) pairs of ALL ranks' observations, the same on every rank, so that every
+            # rank orders the kept family identically (vmm_ba_create_options.structure_obs_*)
+            s_cam = np.ascontiguousarray(structure_obs[0], np.int32).reshape(-1)
+            s_tag = np.ascontiguousarray(structure_obs[1], np.int32).reshape(-1)
+            if len(s_cam) != len(s_tag):
+                raise ValueError("structure_obs arrays differ in length")
+            co.n_structure_obs, co.structure_obs_cam, co.structure_obs_tag = len(s_cam), ip(s_cam), ip(s_tag)
         _lib.check(L.vmm_ba_create(C.byref(p), C.byref(co), C.byref(self._h)))
         self._allreduce_cb = None
 
