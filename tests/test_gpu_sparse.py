@@ -185,3 +185,42 @@ def test_tree_ordering_random_close_up_scenes(monkeypatch, seed):
     _assert_same_run(runs[0][0], runs[1][0], runs[0][1], runs[0][2], runs[1][1], runs[1][2], rtol=1e-8)
     print("seed %d: %d cams x %d tags, elimination %s, tree nodes %d" % (seed, n_cams, n_tags, "cams" if elim == eng.ELIM_CAMERAS else "tags",
                                                                          runs[0][0]["tree_ordering"]))
+
+
+def test_tree_ordering_at_2000_x_1000(oracle, monkeypatch):
+    """The realistic LARGE scene: 2000 images x 1000 tags on a wall, every image sees its 6..10 nearest tags (about 16 000 tag
+    observations).  Its reduced system of 1000 kept poses is as sparse as the small close-up scene's; the reference factors
+    it with a fill-reducing ordering whatever the size (Ceres' sparse normal Cholesky, src/TagReconstructor.cpp:725-738).
+    Round 3 took the tree ordering only up to 48 natural block columns: this scene got the dense 94-column factorisation
+    (3.0 ms).  Now only the non-zero blocks of the factor have a workgroup (109 block columns, ~1300 workgroups, masks of 256
+    bits per block row) and the one-launch kernel takes it.  Checked: the first two LM iterations against the oracle, the whole
+    trajectory against the natural order (the launch-per-column factorisation of the same handle type), no give-up."""
+    from test_gpu_solve import _assert_same_solution
+    from visual_marker_mapping_amd import engine as eng
+    from visual_marker_mapping_amd.synthetic import make_scene
+    s = make_scene(4, neighbors_min=6, neighbors_max=10)
+    assert (len(s.cam_init), len(s.tag_init)) == (2000, 1000) and 10000 < s.n_obs < 25000
+    monkeypatch.delenv("VMM_BA_ORDER", raising=False)
+    tree, cam_t, tag_t, _, _ = _solve(s, 0, None, monkeypatch)
+    assert tree["block_sparse"] == 1 and tree["tree_ordering"] >= 8 and tree["num_sync_timeouts"] == 0
+    assert tree["termination_type"] == eng.CONVERGENCE
+    monkeypatch.setenv("VMM_BA_ORDER", "natural")
+    nat, cam_n, tag_n, _, _ = _solve(s, 0, None, monkeypatch)
+    assert nat["tree_ordering"] == 0 and nat["block_sparse"] == 1
+    _assert_same_run(tree, nat, cam_t, tag_t, cam_n, tag_n, rtol=1e-9)
+    # the first two LM iterations against the oracle (its Schur path on the dense 6000 x 6000 reduced system)
+    monkeypatch.delenv("VMM_BA_ORDER", raising=False)
+    ba = eng.BundleAdjuster(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+    try:
+        two = ba.solve(eng.default_options(robustify=0, max_num_iterations=2), trace_capacity=8)
+        cam2, tag2 = ba.get_state()
+    finally:
+        ba.close()
+    sc = oracle.Scene(s.intr, s.dist, s.cam_init, s.tag_init, s.tag_wh, s.fixed_tag, s.obs_cam, s.obs_tag, s.obs_px)
+    summ, trace = oracle.solve(sc, oracle.default_options(robustify=0, num_threads=8, max_num_iterations=2))
+    assert two["iterations"] == summ["iterations"] == 3
+    for k in range(3):
+        assert two["trace"][k]["step_is_successful"] == trace[k]["step_is_successful"]
+        np.testing.assert_allclose(two["trace"][k]["cost"], trace[k]["cost"], rtol=1e-8)
+        np.testing.assert_allclose(two["trace"][k]["trust_region_radius"], trace[k]["trust_region_radius"], rtol=1e-6)
+    _assert_same_solution(cam2, tag2, sc, s.tag_wh)

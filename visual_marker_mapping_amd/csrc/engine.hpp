@@ -14,6 +14,8 @@ namespace vmm {
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kPart = 32;          // doubles per task partial: 21 (H lower) + 6 (g) + 1 (cost) + pad
 constexpr int kNB = 64;            // dense block size of the reduced system
+constexpr int kDfMaskWords = 4;    // 64-bit words of a block row's structure mask (tree orderings): up to 255 block columns
+constexpr int kDfMaxBlk = 256;
 constexpr int kKT = 16;            // K tile of the MFMA f64 rank-k update (rows of Z per LDS stage)
 constexpr int kST = 128;           // output tile of the rank-k update (the leading dimension is a multiple of it)
 constexpr int kLdsRow = 80;        // LDS row stride (doubles) for 64-wide tiles: rows k, k+1 land in
@@ -192,8 +194,12 @@ struct Engine {
     int32_t* row_of = nullptr;      // [n_f] first row of every kept pose in the reduced system (explicit form only)
     int32_t* pose_of_row = nullptr; // [n_pad] world > 1 with a tree ordering: kept pose of a row of the reduced system, -1: padding
     std::vector<int32_t> h_row_of;  // host copy; empty: kept pose f sits at row 6 f
-    unsigned long long* chol_nz = nullptr;    // [n_blk + 1] block structure of the factor (tree ordering), see DfArgs::nz
-    unsigned char* chol_order = nullptr;      // [n_blk][64] panel order per block column, see DfArgs::order
+    unsigned long long* chol_nz = nullptr;    // [n_blk + 1][kDfMaskWords] block structure of the factor (tree ordering), see DfArgs::nz
+    unsigned char* chol_order = nullptr;      // [n_blk][kDfMaxBlk] panel order per block column, see DfArgs::order
+    int32_t* df_wg = nullptr;                 // [n_df_wg][2] (block column, block row) of the tree-ordered launch's workgroups
+    int32_t* df_slot = nullptr;               // [n_blk][n_blk + 1] slot of a block's slices in df_gran, -1: structurally zero
+    int n_df_wg = 0;
+    size_t df_tree_slots = 0;                 // blocks with published slices under the tree ordering
     bool chol_nz_on = false;                  // off while a call factors the dense, naturally ordered system (covariance)
     std::vector<int32_t> nd_node_first_blk;   // tree ordering: first 64-row block of every node, in elimination order
     int n_row_items = 0;

@@ -77,6 +77,12 @@ namespace vmm {
 // separate triangular-solve phase: after the last round the scaled columns ARE L_ik.
 // (Four columns per round cost 16 x (2 barriers + 2 LDS round trips); eight halve that overhead for
 // the same pivot chain.)
+// block structure of a tree-ordered factor (DfArgs::nz): bit k of block row i
+__device__ __forceinline__ bool nz_bit(const unsigned long long* nz, const int i, const int k)
+{
+    return (nz[kDfMaskWords * i + (k >> 6)] >> (k & 63)) & 1ull;
+}
+
 constexpr int kPs = 9;   // LDS row stride (doubles) of the 64x8 panel buffers: conflict-free rows
 constexpr int kPw = 8;   // columns per round
 
@@ -1264,8 +1270,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain_tree(LmCtl* ctl, const 
     // The blocks of column m below the diagonal.  Dense: all of m+1 .. n_blk-1, and the hop waits for y_{m+1}.  With the
     // factor's block structure (tree ordering): only those with L(j, m) != 0; the nearest one, jp, is the block whose
     // unknowns arrive last (the parent in the elimination tree) and takes the place of m+1; without any, y_m = u_m.
-    // (nz is only given for systems of at most 48 blocks: m < 64)
-    auto below = [&](int jj) { return !nz || ((nz[jj] >> m) & 1ull); };   // L(jj, m) may be non-zero
+    auto below = [&](int jj) { return !nz || nz_bit(nz, jj, m); };   // L(jj, m) may be non-zero
     int jp = m + 1;
     while (jp < n_blk && !below(jp))
         ++jp;
@@ -1507,19 +1512,36 @@ struct DfArgs {
     const unsigned* epoch_word;  // bumped by the back-substitution chain that follows
     unsigned* abort_word;        // == epoch: some workgroup gave up waiting
     unsigned spin_limit;         // polls before a wait gives up (set per launch from LmCtl::spin_limit_df)
-    const unsigned long long* nz;   // block structure of the factor: bit k of nz[i] = L(i, k) may be non-zero (after fill);
-                                    // null: dense.  A workgroup then only consumes the panels its row and column share,
-                                    // a structurally zero tile has no work and publishes nothing (tree orderings)
-    const unsigned char* order;     // with nz: [n_blk][64] the panels of block column j in the order they are expected to
-                                    // be finished (a column of a separator takes the panels of the subtree that is done
+    const unsigned long long* nz;   // block structure of the factor: bit k of row i (kDfMaskWords words per row, up to 255
+                                    // block columns) = L(i, k) may be non-zero (after fill); null: dense.  A workgroup then only
+                                    // consumes the panels its row and column share, a structurally zero tile has no workgroup
+                                    // and no slot for its slices (tree orderings)
+    const unsigned char* order;     // with nz: [n_blk][kDfMaxBlk] the panels of block column j in the order they are expected
+                                    // to be finished (a column of a separator takes the panels of the subtree that is done
                                     // first first, instead of waiting for panel 9 with panels 12-14 already there)
+    const int32_t* wg;              // with nz: [gridDim.x][2] (block column, block row) of every workgroup, panel-major: the
+                                    // non-zero blocks below the diagonal of a column (the right-hand side row last), then the
+                                    // diagonal-only workgroup
+    const int32_t* slot;            // with nz: [n_blk][n_blk + 1] slot of block (k, rb)'s slices in G, -1: structurally zero
 };
 
-// panels k < j that block column j of the factor has an entry in (dense: all of them)
-__device__ __forceinline__ unsigned long long df_panels(const DfArgs& a, int j)
+
+
+// number of panels k < j that block column j of the factor has an entry in (dense: all of them)
+__device__ __forceinline__ int df_num_panels(const DfArgs& a, const int j)
 {
-    const unsigned long long below = (1ull << j) - 1ull;   // j <= 48
-    return a.nz ? (a.nz[j] & below) : below;
+    if (!a.nz)
+        return j;
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < kDfMaskWords; ++w) {
+        const int lo = 64 * w;
+        if (j <= lo)
+            break;
+        const unsigned long long below = (j - lo >= 64) ? ~0ull : ((1ull << (j - lo)) - 1ull);
+        n += __popcll(a.nz[kDfMaskWords * j + w] & below);
+    }
+    return n;
 }
 
 __device__ __forceinline__ double df_value(const unsigned long long lo, const unsigned long long hi)
@@ -1873,9 +1895,11 @@ struct Lds {
 struct SliceMap {
     unsigned long long* G;
     int n_blk;
+    const int32_t* slot;   // tree orderings: [n_blk][n_blk + 1] slot of block (k, rb), only the non-zero blocks have one
     __device__ __forceinline__ unsigned long long* at(int k, int rb, int r) const
     {
-        const int64_t base = (int64_t)k * n_blk - (int64_t)k * (k - 1) / 2 + (rb - k - 1);
+        const int64_t base = slot ? (int64_t)slot[k * (n_blk + 1) + rb]
+                                  : (int64_t)k * n_blk - (int64_t)k * (k - 1) / 2 + (rb - k - 1);
         return G + (base * 8 + r) * kDfSlice;
     }
 };
@@ -2031,7 +2055,7 @@ template <bool HAS_T, bool TREE>
 __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const int lane, const int j, const int R,
                                            const Lds& m, const SliceMap& sm, const unsigned epoch, int* s_timeout, bool& ok)
 {
-    const int n_it = TREE ? 8 * __popcll(df_panels(a, j)) : 8 * j;   // a multiple of 8
+    const int n_it = TREE ? 8 * df_num_panels(a, j) : 8 * j;   // a multiple of 8
     if (n_it > 0) {
         // Two slices are on their way at any time (two register sets): a slice read costs a round trip to the level all
         // XCDs share (~1.0-1.3 us) and with one request in flight that was the pace of a workgroup working off panels that are
@@ -2040,31 +2064,55 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
         SliceRegs ga, gb;
         const bool sweeper = w == 0 || HAS_T;
         const int my_rb = (w == 0) ? j : R;
-        const unsigned char* const ord = TREE ? a.order + 64 * j : nullptr;
+        const unsigned char* const ord = TREE ? a.order + kDfMaxBlk * j : nullptr;
         // TREE: wave 1 sweeps the slices of block row R; where L(R, k) is structurally zero nobody publishes one -- zeros
-        const unsigned long long mine = (!TREE || w == 0 || R >= a.n_blk) ? ~0ull : a.nz[R];
-        auto panel_of = [&](const int it) { return TREE ? (int)ord[it >> 3] : (it >> 3); };
+        const bool mine_all = !TREE || w == 0 || R >= a.n_blk;
+        // What a tree ordering keeps in tables in global memory -- which panel comes at position it >> 3 of this block column's
+        // list, whether block row R has an entry in it, where block (k, my_rb) publishes its slices -- is looked up once per
+        // PANEL (two panels are in use around a panel boundary), not once per slice: three dependent loads in front of every
+        // request cost ~15 % of the slice rate.
+        struct PanelInfo {
+            int pos, k;
+            bool has;
+            unsigned long long* base;
+        };
+        PanelInfo c0{ -1, 0, false, nullptr }, c1{ -1, 0, false, nullptr };
+        auto panel_at = [&](const int it) -> const PanelInfo& {
+            const int pos = it >> 3;
+            if (pos == c0.pos)
+                return c0;
+            if (pos == c1.pos)
+                return c1;
+            c1 = c0;
+            c0.pos = pos;
+            c0.k = TREE ? (int)ord[pos] : pos;
+            c0.has = mine_all || nz_bit(a.nz, R, c0.k);
+            c0.base = c0.has ? sm.at(c0.k, my_rb, 0) : nullptr;
+            return c0;
+        };
         auto request = [&](const int it, SliceRegs& g) {
             if (sweeper && it < n_it) {
-                const int k = panel_of(it);
-                if ((mine >> k) & 1ull)
-                    issue_slice(sm.at(k, my_rb, it & 7), lane, g);
+                const PanelInfo& pi = panel_at(it);
+                if (pi.has)
+                    issue_slice(pi.base + (it & 7) * kDfSlice, lane, g);
             }
         };
         auto consume = [&](const int it, SliceRegs& g, SliceRegs& gn) {
-            const int k = panel_of(it);
-            const bool have = !TREE || ((mine >> k) & 1ull);
+            const PanelInfo pi = sweeper ? panel_at(it) : PanelInfo{ it >> 3, 0, true, nullptr };
+            const int k = pi.k;
+            const bool have = pi.has;
             if (sweeper) {
                 // the panel expected last (dense: the one right before mine) is swept directly instead of probed
                 const bool last_panel = TREE ? it + 8 >= n_it : k == j - 1;
                 bool got = true;
                 if (have && last_panel) {
                     // the next slice belongs to the same panel unless this is the panel's last one
-                    const bool next_too = (it & 7) != 7 && (!TREE || ((mine >> k) & 1ull));
-                    got = wait_slice_pair(sm.at(k, my_rb, it & 7), next_too ? sm.at(k, my_rb, (it & 7) + 1) : nullptr, lane, epoch,
+                    const bool next_too = (it & 7) != 7;
+                    unsigned long long* const sl = pi.base + (it & 7) * kDfSlice;
+                    got = wait_slice_pair(sl, next_too ? sl + kDfSlice : nullptr, lane, epoch,
                                           a.abort_word, g, gn, a.spin_limit);
                 } else if (have) {
-                    got = wait_slice(sm.at(k, my_rb, it & 7), lane, epoch, a.abort_word, false, g, a.spin_limit);
+                    got = wait_slice(pi.base + (it & 7) * kDfSlice, lane, epoch, a.abort_word, false, g, a.spin_limit);
                 }
 #ifdef VMM_STAMPS
                 if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 2)
@@ -2193,7 +2241,7 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
             }
         }
     }, Seq13{});
-    const int n_it = TREE ? 8 * __popcll(df_panels(a, j)) : 8 * j;
+    const int n_it = TREE ? 8 * df_num_panels(a, j) : 8 * j;
     for (int it = 0; it + 1 < n_it; ++it) {
         const double* XJ = m.Xs + (it & 1) * 2 * kDfXs;
         const double* XR = XJ + kDfXs;
@@ -2249,7 +2297,7 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     const int K0 = j * kNB;
     const int R0 = R * kNB;
     const int n_blk = a.n_blk, ld = a.ld, n_pad = a.n_pad;
-    if (TREE && HAS_T && R < n_blk && !((a.nz[R] >> j) & 1ull))
+    if (TREE && HAS_T && R < n_blk && !nz_bit(a.nz, R, j))
         return;   // L(R, j) is structurally zero: nothing to compute, nothing to publish (its consumers know)
     const unsigned epoch = *a.epoch_word + 1u;
     Lds m;
@@ -2278,6 +2326,7 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     SliceMap sm;
     sm.G = a.G;
     sm.n_blk = n_blk;
+    sm.slot = TREE ? a.slot : nullptr;
     __syncthreads();   // s_timeout
     bool ok = true;
     if (w < 2)
@@ -2332,6 +2381,15 @@ __device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
     if (a.ctl->lin_fail)
         return;
     __shared__ __attribute__((aligned(16))) double smem[kDfSmem];
+    if (TREE) {
+        // only the non-zero blocks of the factor have a workgroup (listed panel-major by the host)
+        const int j = a.wg[2 * (int)blockIdx.x], R = a.wg[2 * (int)blockIdx.x + 1];
+        if (R > j)
+            df2::role<true, TREE>(a, j, R, smem);
+        else
+            df2::role<false, TREE>(a, j, j, smem);
+        return;
+    }
     int b = (int)blockIdx.x, j = 0;
     for (; j < a.n_blk; ++j) {
         const int cnt = a.n_blk - j + 1;
@@ -2549,8 +2607,10 @@ static void launch_dataflow(Engine& e, double* S, int n_pad, int ld, LmCtl* ctl,
     a.spin_limit = 0;
     a.nz = (first_blk == 0 && e.chol_nz_on) ? e.chol_nz : nullptr;
     a.order = a.nz ? e.chol_order : nullptr;
+    a.wg = a.nz ? e.df_wg : nullptr;
+    a.slot = a.nz ? e.df_slot : nullptr;
     if (a.nz)
-        hipLaunchKernelGGL(k_chol_dataflow_tree, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
+        hipLaunchKernelGGL(k_chol_dataflow_tree, dim3(e.n_df_wg), dim3(256), 0, e.stream, a);
     else
         hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
 }
@@ -2571,7 +2631,8 @@ void launch_cholesky_solve(Engine& e, double* S, int n_pad, int ld, double* y, L
 {
     const int n_blk = n_pad / kNB;
     const bool chain = n_blk <= e.n_cu && e.flags && e.gran && !e.no_chain && !safe;
-    const int n_df = (chain && e.df_gran && !e.no_dataflow) ? dataflow_blocks(n_blk, e.n_cu) : 0;
+    // a tree-ordered handle: the one-launch kernel whatever the size (only the non-zero blocks have workgroups)
+    const int n_df = (chain && e.df_gran && !e.no_dataflow) ? (e.chol_nz_on ? n_blk : dataflow_blocks(n_blk, e.n_cu)) : 0;
     if (n_df == n_blk) {
         // one launch for the factorisation + forward substitution, one for the back-substitution chain (which
         // bumps the epoch both kernels tag their granules with)

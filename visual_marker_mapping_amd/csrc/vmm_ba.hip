@@ -895,6 +895,83 @@ void vmm_ba_default_create_options(vmm_ba_create_options* o)
     o->world_size = 1;
 }
 
+// ---- block structure of the factor under a tree ordering ---------------------------------------------------------
+// One mask per 64-row block row (kDfMaskWords words: up to 255 block columns), bit k = block (i, k) of the factor may be
+// non-zero: the blocks the kept poses' 6x6 blocks touch (rows = first row of every kept pose, nbr = the co-observation
+// graph), then symbolic fill (eliminating block column k couples every two block rows with an entry in it).  Row nb is the
+// right-hand side row: all ones.
+struct BlkMask {
+    unsigned long long w[kDfMaskWords] = {};
+    void set(int k) { w[k >> 6] |= 1ull << (k & 63); }
+    bool test(int k) const { return (w[k >> 6] >> (k & 63)) & 1ull; }
+};
+
+static std::vector<BlkMask> symbolic_factor(int nb, const std::vector<int32_t>& rows,
+                                            const std::vector<std::vector<int32_t>>& nbr)
+{
+    std::vector<BlkMask> nz((size_t)nb + 1);
+    for (int i = 0; i < nb; ++i)
+        nz[(size_t)i].set(i);
+    const int n_f = (int)rows.size();
+    auto touch = [&](int f1, int f2) {
+        const int r1 = rows[(size_t)f1], r2 = rows[(size_t)f2];
+        for (int bi = r1 / kNB; bi <= (r1 + 5) / kNB; ++bi)
+            for (int bj = r2 / kNB; bj <= (r2 + 5) / kNB; ++bj)
+                nz[(size_t)std::max(bi, bj)].set(std::min(bi, bj));
+    };
+    for (int fq = 0; fq < n_f; ++fq) {
+        touch(fq, fq);
+        for (const int32_t f2 : nbr[(size_t)fq])
+            touch(fq, f2);
+    }
+    for (int k = 0; k < nb; ++k)
+        for (int i = k + 1; i < nb; ++i)
+            if (nz[(size_t)i].test(k))
+                for (int j2 = k + 1; j2 <= i; ++j2)
+                    if (nz[(size_t)j2].test(k))
+                        nz[(size_t)i].set(j2);
+    for (int k = 0; k < nb; ++k)
+        nz[(size_t)nb].set(k);
+    return nz;
+}
+
+// The model of the one-launch kernel the ordering decisions use (microseconds; measured in round 4: a block column's own
+// eight rounds 7.1; a panel's eight slices are 8 of work for the workgroup that applies them, which it does while they are
+// produced -- it is 2.7 behind when the panel ends): when block column j is done if it takes its panels in the order they
+// finish.  Also fills the order and the longest chain of dependent columns.
+static double model_tree_factorisation(int nb, const std::vector<BlkMask>& nz, std::vector<unsigned char>* ord, int* path_max)
+{
+    std::vector<double> t_done((size_t)nb, 0.0);
+    std::vector<int> path((size_t)nb, 1);
+    int pm = 0;
+    static const bool old_model = [] {
+        const char* v = getenv("VMM_BA_TREE_MODEL");
+        return v && !strcmp(v, "r3");
+    }();
+    for (int j2 = 0; j2 < nb; ++j2) {
+        std::vector<int> ks;
+        for (int k = 0; k < j2; ++k)
+            if (nz[(size_t)j2].test(k))
+                ks.push_back(k);
+        std::stable_sort(ks.begin(), ks.end(), [&](int x, int y) { return t_done[(size_t)x] < t_done[(size_t)y]; });
+        double t = 0.0;
+        for (size_t q = 0; q < ks.size(); ++q) {
+            if (ord)
+                (*ord)[(size_t)j2 * kDfMaxBlk + q] = (unsigned char)ks[q];
+            t = old_model ? std::max(t, t_done[(size_t)ks[q]]) + 5.6 : std::max(t + 8.0, t_done[(size_t)ks[q]] + 2.7);
+            path[(size_t)j2] = std::max(path[(size_t)j2], path[(size_t)ks[q]] + 1);
+        }
+        t_done[(size_t)j2] = t + (old_model ? 11.0 : 7.1);
+        pm = std::max(pm, path[(size_t)j2]);
+    }
+    if (path_max)
+        *path_max = pm;
+    double t_end = 0.0;
+    for (const double t : t_done)
+        t_end = std::max(t_end, t);
+    return t_end;
+}
+
 // ---- tree ordering of the kept family (block-sparse path) -------------------------------------------------------
 // Nested dissection of the co-observation graph of the kept poses (two kept poses are neighbours when one eliminated
 // pose sees both: exactly the non-zero blocks of the reduced system).  A part is cut at the breadth-first level (from a
@@ -1371,7 +1448,7 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         const bool forced = ov && !strcmp(ov, "nd"), forbidden = ov && !strcmp(ov, "natural");
         // (the host-side graph work is bounded: 5e7 list entries, and a natural order beyond the one-launch kernel's 48 block
         // columns cannot become a tree order within them)
-        if (e.sparse_schur && layout_free && !forbidden && e.n_f > 1 && e.n_blk >= 4 && e.n_blk <= 48 && e.co_terms <= 5e7) {
+        if (e.sparse_schur && layout_free && !forbidden && e.n_f > 1 && e.n_blk >= 4 && e.co_terms <= 5e7) {
             std::vector<std::vector<int32_t>>& nbr = tree_nbr;
             nbr.assign((size_t)e.n_f, {});
             for (int q = 0; q < e.n_e; ++q)
@@ -1405,55 +1482,32 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
             // Worth it?  The factorisation is a chain of dependent block columns (~11 us each): the longest chain under
             // the tree ordering (block structure after symbolic fill, nodes as dense blocks: an upper bound) against the
             // n_blk of the natural order.  Taken when it is at most 0.7 of it (VMM_BA_ORDER=nd: always).
-            // (the block structure is kept as one 64-bit mask per block row and chol_order as [n_blk][64]: 64 block columns
-            // at most, whatever VMM_BA_DF_MAX_WG or the number of compute units would allow)
-            bool take = nodes.size() > 2 && n_pad_nd / kNB <= 64
-                        && dataflow_workgroups(n_pad_nd / kNB) <= dataflow_max_workgroups(e.n_cu);
-            if (take && !forced) {
-                const int nb = n_pad_nd / kNB;
-                std::vector<unsigned long long> nzr((size_t)nb, 0ull);
+            // (the block structure is kept as kDfMaskWords 64-bit words per block row, the panel order in bytes: at most 255
+            // block columns; only the non-zero blocks of the factor get a workgroup, so the one-launch kernel takes the
+            // system whatever its order -- counted below)
+            const int nb = n_pad_nd / kNB;
+            bool take = nodes.size() > 2 && nb <= kDfMaxBlk - 1;
+            if (take) {
+                const std::vector<BlkMask> nzr = symbolic_factor(nb, rows, nbr);
+                int n_wg = nb;
                 for (int i = 0; i < nb; ++i)
-                    nzr[(size_t)i] = 1ull << i;
-                for (int fq = 0; fq < e.n_f; ++fq)
-                    for (const int32_t f2 : nbr[(size_t)fq]) {
-                        const int r1 = rows[(size_t)fq], r2 = rows[(size_t)f2];
-                        for (int bi = r1 / kNB; bi <= (r1 + 5) / kNB; ++bi)
-                            for (int bj = r2 / kNB; bj <= (r2 + 5) / kNB; ++bj)
-                                nzr[(size_t)std::max(bi, bj)] |= 1ull << std::min(bi, bj);
-                    }
-                std::vector<int> path((size_t)nb, 1);
+                    for (int k = 0; k < i; ++k)
+                        n_wg += nzr[(size_t)i].test(k) ? 1 : 0;
+                n_wg += nb;   // the right-hand side row's block of every column
                 int path_max = 1;
-                for (int k = 0; k < nb; ++k) {
-                    for (int i = k + 1; i < nb; ++i)
-                        if ((nzr[(size_t)i] >> k) & 1ull) {
-                            for (int j2 = k + 1; j2 <= i; ++j2)
-                                if ((nzr[(size_t)j2] >> k) & 1ull)
-                                    nzr[(size_t)i] |= 1ull << j2;
-                            path[(size_t)i] = std::max(path[(size_t)i], path[(size_t)k] + 1);
-                        }
-                    path_max = std::max(path_max, path[(size_t)k]);
-                }
-                // ... and the model of the kernel (5.6 us to apply a panel's slices once they are there, 11 us for a block
-                // column's own factorisation, panels taken in the order they finish) must agree: a separator column with
-                // many panels can be bound by applying them, not by the chain
-                std::vector<double> t_done((size_t)nb, 0.0);
-                for (int j2 = 0; j2 < nb; ++j2) {
-                    std::vector<double> ready;
-                    for (int k = 0; k < j2; ++k)
-                        if ((nzr[(size_t)j2] >> k) & 1ull)
-                            ready.push_back(t_done[(size_t)k]);
-                    std::sort(ready.begin(), ready.end());
-                    double t = 0.0;
-                    for (const double r : ready)
-                        t = std::max(t, r) + 5.6;
-                    t_done[(size_t)j2] = t + 11.0;
-                }
-                const double t_tree = t_done[(size_t)nb - 1], t_nat = 11.0 * e.n_blk;
-                take = path_max * 10 <= e.n_blk * 7 && t_tree <= 0.9 * t_nat;
+                const double t_tree = model_tree_factorisation(nb, nzr, nullptr, &path_max);
+                // natural order: the one-launch kernel up to 48 block columns (~9.8 us each), one launch per column beyond
+                // (~32 us each at 94 columns)
+                const double t_nat = e.n_blk <= 48 ? 9.8 * e.n_blk : 32.0 * e.n_blk;
+                static const int max_wg = [] {
+                    const char* v = getenv("VMM_BA_TREE_MAX_WG");
+                    return v ? atoi(v) : 16384;
+                }();
+                take = n_wg <= max_wg && (forced || (path_max * 10 <= e.n_blk * 7 && t_tree <= 0.9 * t_nat));
                 if (getenv("VMM_BA_DEBUG"))
                     fprintf(stderr, "[vmm_ba debug] tree ordering candidate: longest chain %d of %d block columns against %d in "
-                                    "natural order, modelled %.0f against %.0f us -> %s\n", path_max, nb, e.n_blk, t_tree, t_nat,
-                            take ? "taken" : "not taken");
+                                    "natural order, %d workgroups, modelled %.0f against %.0f us -> %s\n", path_max, nb, e.n_blk,
+                            n_wg, t_tree, t_nat, take ? "taken" : "not taken");
             }
             if (take) {
                 e.h_row_of = rows;
@@ -1644,72 +1698,56 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         if ((rc = upload(e, e.pair_terms, tt))) return fail(rc);
         if ((rc = upload(e, e.row_items, items))) return fail(rc);
         if (!e.h_row_of.empty()) {
-            // Block structure of the factor under the tree ordering: the 64-row blocks a pair's 6x6 block touches, then
-            // symbolic fill (eliminating block column k couples every two block rows that have an entry in it).  From
-            // ALL observations: an observation mask only removes entries.
-            std::vector<unsigned long long> nzr((size_t)e.n_blk + 1, 0ull);
-            for (int i = 0; i < e.n_blk; ++i)
-                nzr[(size_t)i] |= 1ull << i;
-            // (the co-observation graph the ordering was made from -- all ranks' with world > 1: the summed system has an
-            // entry wherever ANY rank has one -- plus every pose's own block)
-            for (int fq = 0; fq < e.n_f; ++fq) {
-                std::vector<int32_t> with_self(tree_nbr[(size_t)fq]);
-                with_self.push_back(fq);
-                for (const int32_t f2 : with_self) {
-                    const int r1 = e.h_row_of[(size_t)fq], r2 = e.h_row_of[(size_t)f2];
-                    for (int bi = r1 / kNB; bi <= (r1 + 5) / kNB; ++bi)
-                        for (int bj = r2 / kNB; bj <= (r2 + 5) / kNB; ++bj)
-                            nzr[(size_t)std::max(bi, bj)] |= 1ull << std::min(bi, bj);
-                }
-            }
-            for (int k = 0; k < e.n_blk; ++k)
-                for (int i = k + 1; i < e.n_blk; ++i)
-                    if ((nzr[(size_t)i] >> k) & 1ull)
-                        for (int j2 = k + 1; j2 <= i; ++j2)
-                            if ((nzr[(size_t)j2] >> k) & 1ull)
-                                nzr[(size_t)i] |= 1ull << j2;
-            nzr[(size_t)e.n_blk] = ~0ull;   // the right-hand side row
-            if ((rc = dev_alloc(e, &e.chol_nz, nzr.size()))) return fail(rc);
-            if ((rc = upload(e, e.chol_nz, nzr))) return fail(rc);
+            // Block structure of the factor under the tree ordering (symbolic_factor): from the co-observation graph the
+            // ordering was made from -- ALL observations (an observation mask only removes entries), all ranks' with
+            // world > 1 (the summed system has an entry wherever any rank has one).
+            const std::vector<BlkMask> nzr = symbolic_factor(e.n_blk, e.h_row_of, tree_nbr);
+            std::vector<unsigned long long> nzw((size_t)(e.n_blk + 1) * kDfMaskWords);
+            for (int i = 0; i <= e.n_blk; ++i)
+                for (int w = 0; w < kDfMaskWords; ++w)
+                    nzw[(size_t)i * kDfMaskWords + w] = nzr[(size_t)i].w[w];
+            if ((rc = dev_alloc(e, &e.chol_nz, nzw.size()))) return fail(rc);
+            if ((rc = upload(e, e.chol_nz, nzw))) return fail(rc);
             // In which order does block column j take the panels it depends on?  In the order they are expected to be
-            // finished, from a model of the kernel: a panel's slices cost ~5.6 us to apply once they are there, a
-            // block column's own factorisation ~11 us.
-            std::vector<unsigned char> ord((size_t)e.n_blk * 64, 0);
-            std::vector<double> t_done((size_t)e.n_blk, 0.0);
+            // finished, from the model of the kernel.
+            std::vector<unsigned char> ord((size_t)e.n_blk * kDfMaxBlk, 0);
             int path_max = 0;
-            std::vector<int> path((size_t)e.n_blk, 1);
-            for (int j2 = 0; j2 < e.n_blk; ++j2) {
-                std::vector<int> ks;
-                for (int k = 0; k < j2; ++k)
-                    if ((nzr[(size_t)j2] >> k) & 1ull)
-                        ks.push_back(k);
-                std::stable_sort(ks.begin(), ks.end(), [&](int x, int y) { return t_done[(size_t)x] < t_done[(size_t)y]; });
-                double t = 0.0;
-                for (size_t q = 0; q < ks.size(); ++q) {
-                    ord[(size_t)j2 * 64 + q] = (unsigned char)ks[q];
-                    t = std::max(t, t_done[(size_t)ks[q]]) + 5.6;
-                    path[(size_t)j2] = std::max(path[(size_t)j2], path[(size_t)ks[q]] + 1);
-                }
-                t_done[(size_t)j2] = t + 11.0;
-                path_max = std::max(path_max, path[(size_t)j2]);
-            }
+            const double t_model = model_tree_factorisation(e.n_blk, nzr, &ord, &path_max);
             if ((rc = dev_alloc(e, &e.chol_order, ord.size()))) return fail(rc);
             if ((rc = upload(e, e.chol_order, ord))) return fail(rc);
-            if (getenv("VMM_BA_DEBUG"))
-                fprintf(stderr, "[vmm_ba debug] factor: longest chain %d of %d block columns, modelled %.0f us\n", path_max,
-                        e.n_blk, t_done[(size_t)e.n_blk - 1]);
+            // The launch: one workgroup per non-zero block below the diagonal (the right-hand side row's last) and the
+            // diagonal-only workgroup, panel-major -- a workgroup only ever waits for workgroups in front of it -- and one
+            // slot of published slices per block that has a workgroup.
+            std::vector<int32_t> wg, slot((size_t)e.n_blk * (e.n_blk + 1), -1);
+            int32_t n_slots = 0;
+            for (int j2 = 0; j2 < e.n_blk; ++j2) {
+                for (int r = j2 + 1; r <= e.n_blk; ++r)
+                    if (r == e.n_blk || nzr[(size_t)r].test(j2)) {
+                        wg.push_back(j2);
+                        wg.push_back(r);
+                        slot[(size_t)j2 * (e.n_blk + 1) + r] = n_slots++;
+                    }
+                wg.push_back(j2);
+                wg.push_back(j2);
+            }
+            e.n_df_wg = (int)(wg.size() / 2);
+            e.df_tree_slots = (size_t)n_slots;
+            if ((rc = dev_alloc(e, &e.df_wg, wg.size()))) return fail(rc);
+            if ((rc = upload(e, e.df_wg, wg))) return fail(rc);
+            if ((rc = dev_alloc(e, &e.df_slot, slot.size()))) return fail(rc);
+            if ((rc = upload(e, e.df_slot, slot))) return fail(rc);
             e.chol_nz_on = true;
             if (getenv("VMM_BA_DEBUG")) {
-                int nzb = 0;
-                for (int i = 0; i < e.n_blk; ++i)
-                    nzb += __builtin_popcountll(nzr[(size_t)i] & ((2ull << i) - 1ull));
-                fprintf(stderr, "[vmm_ba debug] factor structure: %d of %d lower blocks\n", nzb, e.n_blk * (e.n_blk + 1) / 2);
-                for (int i = 0; i < e.n_blk; ++i) {
-                    fprintf(stderr, "[vmm_ba debug]   %2d ", i);
-                    for (int k = 0; k <= i; ++k)
-                        fputc(((nzr[(size_t)i] >> k) & 1ull) ? 'x' : '.', stderr);
-                    fputc('\n', stderr);
-                }
+                fprintf(stderr, "[vmm_ba debug] factor: longest chain %d of %d block columns, modelled %.0f us, %d workgroups, "
+                                "%d of %d lower blocks\n", path_max, e.n_blk, t_model, e.n_df_wg, n_slots - e.n_blk + e.n_blk,
+                        e.n_blk * (e.n_blk + 1) / 2);
+                if (e.n_blk <= 64)
+                    for (int i = 0; i < e.n_blk; ++i) {
+                        fprintf(stderr, "[vmm_ba debug]   %2d ", i);
+                        for (int k = 0; k <= i; ++k)
+                            fputc(nzr[(size_t)i].test(k) ? 'x' : '.', stderr);
+                        fputc('\n', stderr);
+                    }
             }
         }
         if (e.explicit_pairs) {
@@ -1748,8 +1786,12 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
     if ((rc = dev_alloc(e, &e.flags, 264))) return fail(rc);
     if ((rc = dev_alloc(e, &e.gran, (size_t)2 * e.ldz))) return fail(rc);
     {
+        // published slices of the one-launch factorisation: 64 KB per block below the diagonal (dense: of the block columns
+        // that kernel takes; tree ordering: of the non-zero blocks, and of the dense kernel's share when the handle is
+        // switched to the natural dense system for a call)
         const size_t nd = e.no_dataflow ? 0 : (size_t)dataflow_blocks(e.n_blk, e.n_cu);
-        if (nd > 0 && (rc = dev_alloc(e, &e.df_gran, nd * (nd + 1) / 2 * 8 * 1024)))
+        const size_t slots = std::max(nd * (nd + 1) / 2, e.no_dataflow ? (size_t)0 : e.df_tree_slots);
+        if (slots > 0 && (rc = dev_alloc(e, &e.df_gran, slots * 8 * 1024)))
             return fail(rc);
     }
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
