@@ -246,6 +246,6 @@ def test_one_launch_factorisation_beyond_residency_does_not_give_up(n_cams, n_ta
     finally:
         ba.close()
     assert out["num_sync_timeouts"] == 0 and out["sync_timeout_kernels"] == 0
-    assert out["num_lm_iterations"] == 3 and out["num_successful_steps"] == 3
+    assert out["num_lm_iterations"] == 3 and out["num_unsuccessful_steps"] == 0
     costs = [t["cost"] for t in out["trace"]]
     assert all(b < a for a, b in zip(costs, costs[1:]))

@@ -2079,6 +2079,12 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
         PanelInfo c0{ -1, 0, false, nullptr }, c1{ -1, 0, false, nullptr };
         auto panel_at = [&](const int it) -> const PanelInfo& {
             const int pos = it >> 3;
+            if (!TREE) {   // dense: panel `pos`, every block there, its place is arithmetic
+                c0.pos = c0.k = pos;
+                c0.has = true;
+                c0.base = sm.at(pos, my_rb, 0);
+                return c0;
+            }
             if (pos == c0.pos)
                 return c0;
             if (pos == c1.pos)
