@@ -302,7 +302,7 @@ def main():
         # (tools/gpu_final.sh + tools/pmc_to_traffic.py: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
         # same command, gfx950 x2 read correction calibrated on k_cost's known 7.2 MB); traffic_source says so
         traffic = {}
-        tname = "r03_pmc_traffic.json"
+        tname = "r04_pmc_traffic.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         # the committed counters are of the headline command only: dense elimination of the standard 500 x 200 scene
         if (a.config == 2 and standard_scene and not kt.get("schur_sparse") and not last.get("tree_ordering")
