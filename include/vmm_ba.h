@@ -313,7 +313,8 @@ int vmm_ba_pose_plus(int64_t n, const double* qt, const double* delta, double* o
 /* Diagnostic (can the reduced-system assembly hide behind the factorisation?): ms[0] rank-k update + sum
  * alone, ms[1] factorisation + triangular solves alone, ms[2] both back to back on one stream, ms[3] both at once on
  * two streams (no data dependency between them in this measurement), ms[4] the factorisation's own duration in that
- * concurrent run.  Dense elimination, one GPU. */
+ * concurrent run, ms[5] the rank-k update + sum's; ms[6], ms[7]: total and factorisation when the rank-k update is
+ * enqueued first.  ms holds 8 doubles.  Dense elimination, one GPU. */
 int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms);
 
 /* Test hook, host logic only (no device needed): the launch schedule of the launch-per-column Cholesky

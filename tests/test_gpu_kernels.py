@@ -54,6 +54,23 @@ def test_mfma_f64_syrk_matches_numpy(eng):
             np.testing.assert_allclose(Cg, ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_syrk_few_tiles_both_kernels(eng, monkeypatch, wide):
+    """Few tiles (at most 64): k_syrk_wide (one 8-wave workgroup per CU, balanced diagonal tiles, in-workgroup sum of the
+    two K halves) and, with VMM_BA_SYRK_WIDE=0, the two-workgroups-per-CU kernel -- the headline shape 3000 x 1217, K ranges
+    of odd length, a single 16-row stage, a lone diagonal tile."""
+    monkeypatch.setenv("VMM_BA_SYRK_WIDE", wide)
+    rng = np.random.default_rng(77)
+    for k, n in [(3000, 1217), (330, 520), (16, 128), (48, 1000), (1000, 129)]:
+        Zi = np.round(rng.standard_normal((k, n)) * 3.0)   # integer-valued: exact whatever the summation order
+        np.testing.assert_array_equal(eng.dense_syrk(Zi), Zi.T @ Zi)
+        Z = rng.standard_normal((k, n))
+        C = eng.dense_syrk(Z)
+        ref = Z.T @ Z
+        np.testing.assert_allclose(C, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+        np.testing.assert_array_equal(C, eng.dense_syrk(Z))
+
+
 def test_blocked_cholesky_solve_matches_numpy(eng):
     rng = np.random.default_rng(2)
     for n in (5, 64, 65, 200, 333, 1200):

@@ -99,6 +99,7 @@ struct SyrkPlan {
     int32_t *tile_bi = nullptr, *tile_bj = nullptr, *wg_seg0 = nullptr, *tile_seg0 = nullptr;
     int64_t *wg_u0 = nullptr, *wg_u1 = nullptr;   // [n_wg] unit range of each workgroup (by blockIdx)
     double* partials = nullptr;   // [n_segments][kST*kST]
+    bool wide = false;            // k_syrk_wide: one 8-wave workgroup per CU, one tile per workgroup (few tiles)
 };
 
 struct Engine {

@@ -292,6 +292,158 @@ __global__ __launch_bounds__(256, 2) void k_syrk_streamk(const LmCtl* ctl, const
     }
 }
 
+// ---- the same product with ONE 8-wave workgroup per CU (few tiles: 500 x 200 has 55 on 256 CUs) -------------------
+//
+// k_syrk_streamk fills the chip with two 4-wave workgroups per CU and nine K slices per tile: 495 partial tiles of
+// 128 KB, written in one burst at the end (13 us of a 104 us launch) and read back by k_reduce_partials.  Here the two
+// workgroups of a CU are one: waves 0-3 multiply rows 0-15 of every 32-row stage, waves 4-7 rows 16-31, and the two
+// halves add their accumulators through the LDS before the one partial tile of the workgroup is stored -- half the
+// partial tiles (3-5 per output tile), half the store burst, half of what the reduction reads.
+// A diagonal tile needs only the 36 MFMA tiles on and below its diagonal: wave w of a half takes tile rows w and 7 - w of
+// the 8 x 8 grid (w + 1 and 8 - w tiles: nine each), instead of one 64 x 64 quadrant each with the upper one dead and the
+// lower one setting the pace; the host plan gives a diagonal tile 9/16 of the workgroups of an off-diagonal one.
+// The strictly upper MFMA tiles inside the two diagonal 64 x 64 blocks are written as mirrors of the lower ones, so the
+// reduction finds the full diagonal blocks it found before.
+constexpr int kWideRows = 2 * kSyrkKT;
+constexpr int kWideStage = kWideRows * kSyrkRow;   // doubles per operand stage
+
+template <bool DIAG, int W>
+struct WideTiles {
+    static constexpr int NT = DIAG ? 9 : 16, NA = DIAG ? 2 : 4, NB = DIAG ? 8 - W : 4;
+    static __device__ __host__ constexpr int arow(int i) { return DIAG ? (i == 0 ? W : 7 - W) : 4 * (W >> 1) + i; }
+    static __device__ __host__ constexpr int bcol(int j) { return DIAG ? j : 4 * (W & 1) + j; }
+    static __device__ __host__ constexpr int ai(int n) { return DIAG ? (n <= W ? 0 : 1) : (n >> 2); }
+    static __device__ __host__ constexpr int bi(int n) { return DIAG ? (n <= W ? n : n - (W + 1)) : (n & 3); }
+};
+
+template <bool DIAG, int W>
+__device__ __forceinline__ void syrk_wide_item(const double* __restrict__ Z, const int ldz, const int I0, const int J0,
+                                               const int kt0, const int kt1, double* smem, double* __restrict__ Cb)
+{
+    using T = WideTiles<DIAG, W>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int g = tid >> 8;             // which 16 rows of a stage this wave multiplies
+    const int lr = tid >> 5;            // 0..15 (+16 for the second half of a stage)
+    const int lc = (tid & 31) * 4;      // 0..124
+    const int fk = lane >> 4, fi = lane & 15;
+    double* const As = smem;                     // [2][kWideStage]
+    double* const Bs = smem + 2 * kWideStage;    // [2][kWideStage]
+    double4_t acc[T::NT];
+#pragma unroll
+    for (int n = 0; n < T::NT; ++n)
+        acc[n] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+    double4_t va[2], vb[2];
+    auto gload = [&](const int kt) {   // 16-row units kt, kt + 1; a unit at or behind kt1 is not this item's: zeros
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            va[h] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+            vb[h] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+            if (kt + h < kt1) {
+                const double* zr = Z + (int64_t)((kt + h) * kSyrkKT + lr) * ldz;
+                va[h] = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
+                vb[h] = *reinterpret_cast<const double4_t*>(zr + J0 + lc);   // diagonal tile: the same lines
+            }
+        }
+    };
+    auto lstore = [&](const int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<double4_t*>(&As[buf * kWideStage + (lr + 16 * h) * kSyrkRow + lc]) = va[h];
+            *reinterpret_cast<double4_t*>(&Bs[buf * kWideStage + (lr + 16 * h) * kSyrkRow + lc]) = vb[h];
+        }
+    };
+    gload(kt0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        const bool more = kt + 2 < kt1;
+        if (more)
+            gload(kt + 2);   // the next stage's loads fly while this stage's MFMAs issue
+        const double* Ap = As + buf * kWideStage + g * kSyrkKT * kSyrkRow;
+        const double* Bp = Bs + buf * kWideStage + g * kSyrkKT * kSyrkRow;
+#pragma unroll
+        for (int ks = 0; ks < kSyrkKT / 4; ++ks) {
+            const int row = (ks * 4 + fk) * kSyrkRow;
+            double a[T::NA], b[T::NB];
+#pragma unroll
+            for (int i = 0; i < T::NA; ++i)
+                a[i] = Ap[row + 16 * T::arow(i) + fi];
+#pragma unroll
+            for (int j = 0; j < T::NB; ++j)
+                b[j] = Bp[row + 16 * T::bcol(j) + fi];
+#pragma unroll
+            for (int n = 0; n < T::NT; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T::ai(n)], b[T::bi(n)], acc[n], 0, 0, 0);
+        }
+        if (more)
+            lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // The two halves exchange half of their accumulators through the LDS (dead now: the loop ends with a barrier); each
+    // then holds the sums of half of the wave's MFMA tiles (own + other: the same bits either way) and stores those.
+    constexpr int H = T::NT / 2;
+    double* const X = smem + (size_t)W * 16 * 256;   // [wave of the half][tile 0..15][4][64]
+#pragma unroll
+    for (int n = 0; n < T::NT; ++n)
+        if ((n < H) == (g == 1)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                X[(n * 4 + r) * 64 + lane] = acc[n][r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < T::NT; ++n)
+        if ((n < H) == (g == 0)) {
+            const int tr = T::arow(T::ai(n)), tc = T::bcol(T::bi(n));
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[n][r] + X[(n * 4 + r) * 64 + lane];
+                Cb[(16 * tr + fk + 4 * r) * kSyrkT + 16 * tc + fi] = v[r];
+            }
+            if (DIAG && tr > tc && (tr >> 2) == (tc >> 2)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cb[(16 * tc + fi) * kSyrkT + 16 * tr + fk + 4 * r] = v[r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(512, 1) void k_syrk_wide(const LmCtl* ctl, const double* __restrict__ Z, int ldz, SyrkPlanDev pl)
+{
+    if (ctl && ctl->done)
+        return;
+    __shared__ __attribute__((aligned(16))) double smem[4 * kWideStage];   // 144 KB
+    static_assert(4 * kWideStage >= 4 * 16 * 256, "the accumulator exchange must fit into the stage buffers");
+    const int gidx = blockIdx.x;
+    const int64_t u = pl.wg_u0[gidx], u_end = pl.wg_u1[gidx];
+    if (u >= u_end)
+        return;
+    const int t = (int)(u / pl.n_kt);
+    const int kt0 = (int)(u % pl.n_kt), kt1 = kt0 + (int)(u_end - u);   // one tile per workgroup (host plan)
+    const int I0 = pl.tile_bi[t] * kSyrkT, J0 = pl.tile_bj[t] * kSyrkT;
+    double* Cb = pl.partials + (size_t)pl.wg_seg0[gidx] * kSyrkTile;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) & 3);
+    if (I0 == J0) {
+        switch (w) {
+        case 0: syrk_wide_item<true, 0>(Z, ldz, I0, J0, kt0, kt1, smem, Cb); break;
+        case 1: syrk_wide_item<true, 1>(Z, ldz, I0, J0, kt0, kt1, smem, Cb); break;
+        case 2: syrk_wide_item<true, 2>(Z, ldz, I0, J0, kt0, kt1, smem, Cb); break;
+        default: syrk_wide_item<true, 3>(Z, ldz, I0, J0, kt0, kt1, smem, Cb); break;
+        }
+    } else {
+        switch (w) {
+        case 0: syrk_wide_item<false, 0>(Z, ldz, I0, J0, kt0, kt1, smem, Cb); break;
+        case 1: syrk_wide_item<false, 1>(Z, ldz, I0, J0, kt0, kt1, smem, Cb); break;
+        case 2: syrk_wide_item<false, 2>(Z, ldz, I0, J0, kt0, kt1, smem, Cb); break;
+        default: syrk_wide_item<false, 3>(Z, ldz, I0, J0, kt0, kt1, smem, Cb); break;
+        }
+    }
+}
+
 struct DiagArgs {        // kept family's damped diagonal blocks and rhs, added in the same pass on one GPU
     const double* H_F;
     const double* g_F;
@@ -662,7 +814,9 @@ void launch_elim(Engine& e)
 
 void launch_syrk_plan(hipStream_t st, const LmCtl* ctl, const double* Z, int ldz, const SyrkPlan& p)
 {
-    if (p.n_wg > 0)
+    if (p.n_wg > 0 && p.wide)
+        hipLaunchKernelGGL(k_syrk_wide, dim3(p.n_wg), dim3(512), 0, st, ctl, Z, ldz, plan_dev(p));
+    else if (p.n_wg > 0)
         hipLaunchKernelGGL(k_syrk_streamk, dim3(p.n_wg), dim3(256), 0, st, ctl, Z, ldz, plan_dev(p));
 }
 
@@ -863,6 +1017,7 @@ int preload_schur_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_schur_pairs)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_fill_lower)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_syrk_streamk)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_syrk_wide)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<true>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_reduce_partials<false>)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_unpack_diag)) != hipSuccess;

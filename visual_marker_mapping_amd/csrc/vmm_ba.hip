@@ -271,6 +271,57 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
         }
         bi.swap(bi2);
         bj.swap(bj2);
+        // Round 4: one 8-wave workgroup per CU (k_syrk_wide), one K slice of ONE tile each; a diagonal tile costs 9/16 of
+        // an off-diagonal one there and gets as many fewer workgroups.  500 x 200: 45 x 5 + 10 x 3 = 255 workgroups on
+        // 256 CUs, 255 partial tiles instead of 495.  VMM_BA_SYRK_WIDE=0: the two-workgroups-per-CU kernel below.
+        const bool want_wide = !(getenv("VMM_BA_SYRK_WIDE") && getenv("VMM_BA_SYRK_WIDE")[0] == '0');
+        if (want_wide && !getenv("VMM_BA_SYRK_SLICES") && !getenv("VMM_BA_SYRK_WG_PER_CU")) {
+            int n_diag = 0;
+            for (int t = 0; t < p.n_tiles; ++t)
+                n_diag += bi[t] == bj[t];
+            const int n_off = p.n_tiles - n_diag;
+            const double kDiagCost = 9.0 / 16.0;
+            const int max_w = std::max(1, p.n_kt / 2);   // at least one 32-row stage per workgroup
+            int w_off = (int)std::floor(hw / (n_off + kDiagCost * n_diag));
+            w_off = std::max(1, std::min(w_off, max_w));
+            int w_diag = std::max(1, std::min((int)std::lround(kDiagCost * w_off), max_w));
+            while (w_off > 1 && (int64_t)w_off * n_off + (int64_t)w_diag * n_diag > hw) {
+                --w_off;
+                w_diag = std::max(1, std::min((int)std::lround(kDiagCost * w_off), max_w));
+            }
+            std::vector<int> w_of((size_t)p.n_tiles);
+            int n_items = 0;
+            for (int t = 0; t < p.n_tiles; ++t) {
+                w_of[t] = bi[t] == bj[t] ? w_diag : w_off;
+                tile_seg0[t] = n_items;
+                n_items += w_of[t];
+            }
+            tile_seg0[p.n_tiles] = n_items;
+            // items slice-major (all tiles' first slices, then the second ones, ...): XCD x takes the x-th run of them, so
+            // the workgroups an XCD holds sweep the same rows of Z
+            std::vector<std::pair<int, int>> items;
+            for (int sl = 0; sl < std::max(w_off, w_diag); ++sl)
+                for (int t = 0; t < p.n_tiles; ++t)
+                    if (sl < w_of[t])
+                        items.emplace_back(t, sl);
+            const int per_x = (n_items + n_xcd - 1) / n_xcd;
+            p.n_wg = per_x * n_xcd;
+            p.wide = true;
+            wg_u0.assign((size_t)p.n_wg, 0);
+            wg_u1.assign((size_t)p.n_wg, 0);
+            wg_seg0.assign((size_t)p.n_wg, 0);
+            for (int b = 0; b < p.n_wg; ++b) {
+                const int x = b % n_xcd, j = b / n_xcd;
+                const int it = x * per_x + j;
+                if (j >= per_x || it >= n_items)
+                    continue;
+                const int t = items[(size_t)it].first, sl = items[(size_t)it].second;
+                wg_u0[b] = (int64_t)t * p.n_kt + (int64_t)p.n_kt * sl / w_of[t];
+                wg_u1[b] = (int64_t)t * p.n_kt + (int64_t)p.n_kt * (sl + 1) / w_of[t];
+                wg_seg0[b] = tile_seg0[t] + sl;
+            }
+            seg = n_items;
+        } else {
         // K slices per tile: as many as fit the workgroup slots (two per CU), so that every SIMD carries about the
         // same number of MFMAs (8 slices on 440 of 512 slots left 184 CUs with two workgroups and 72 with one)
         int n_sl = (int)std::min<int64_t>(slots / p.n_tiles, p.n_kt);
@@ -296,6 +347,7 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
         for (int t = 0; t <= p.n_tiles; ++t)
             tile_seg0[t] = n_sl * t;
         seg = n_sl * p.n_tiles;
+        }
     } else {
     const int64_t full_rounds = (xcd_rounds && slots % n_xcd == 0) ? p.n_tiles / slots : 0;
     const int64_t tiles_a = full_rounds * slots;                      // one tile per workgroup
@@ -2742,10 +2794,10 @@ int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
     HIP_TRY(hipStreamSynchronize(e.stream));
     double* S2 = nullptr;
     hipStream_t sb = nullptr;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     hipError_t err = hipMalloc((void**)&S2, sizeof(double) * (size_t)e.ldz * e.ldz);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && err == hipSuccess; ++i)
+    for (int i = 0; i < 5 && err == hipSuccess; ++i)
         err = hipEventCreate(&ev[i]);
     auto reset_flags = [&]() -> hipError_t {
         hipError_t r = hipMemcpy(e.ctl_host, e.ctl, sizeof(LmCtl), hipMemcpyDeviceToHost);
@@ -2755,9 +2807,9 @@ int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
         e.ctl_host->sync_timeout = 0;
         return hipMemcpy(e.ctl, e.ctl_host, sizeof(LmCtl), hipMemcpyHostToDevice);
     };
-    double acc[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+    double acc[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
     for (int r = 0; r < reps + 1 && err == hipSuccess; ++r) {   // repetition 0 is untimed
-        float t[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+        float t[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
         // (0) rank-k update + sum (leaves a valid S), (1) factorisation + solves
         if ((err = reset_flags()) != hipSuccess) break;
         (void)hipEventRecord(ev[0], e.stream);
@@ -2787,8 +2839,27 @@ int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
         if ((err = hipEventSynchronize(ev[2])) != hipSuccess) break;
         (void)hipEventElapsedTime(&t[3], ev[0], ev[2]);
         (void)hipEventElapsedTime(&t[4], ev[0], ev[3]);
+        (void)hipEventElapsedTime(&t[5], ev[0], ev[1]);
+        // (6) the same with the rank-k update enqueued FIRST (its 495 workgroups take their slots, the factorisation's
+        // workgroups follow as slots fall free)
+        if ((err = reset_flags()) != hipSuccess) break;
+        launch_syrk_reduced(e);
+        if ((err = hipStreamSynchronize(e.stream)) != hipSuccess) break;
+        (void)hipEventRecord(ev[0], e.stream);
+        (void)hipStreamWaitEvent(sb, ev[0], 0);
+        launch_syrk_plan(sb, e.ctl, e.Z, e.ldz, e.syrk);
+        launch_reduce_plan(sb, e.ctl, e.syrk, e.ldz, e.n_pad + 1, S2);
+        (void)hipEventRecord(ev[1], sb);
+        (void)hipEventRecord(ev[4], e.stream);
+        launch_cholesky_solve(e, e.S, e.n_pad, e.ldz, e.yf, e.ctl);
+        (void)hipEventRecord(ev[3], e.stream);
+        (void)hipStreamWaitEvent(e.stream, ev[1], 0);
+        (void)hipEventRecord(ev[2], e.stream);
+        if ((err = hipEventSynchronize(ev[2])) != hipSuccess) break;
+        (void)hipEventElapsedTime(&t[6], ev[0], ev[2]);
+        (void)hipEventElapsedTime(&t[7], ev[4], ev[3]);
         if (r > 0)
-            for (int i = 0; i < 5; ++i)
+            for (int i = 0; i < 8; ++i)
                 acc[i] += t[i];
     }
     if (err == hipSuccess)
@@ -2801,7 +2872,7 @@ int vmm_ba_debug_overlap(vmm_ba_handle h, int reps, double* ms)
         set_error(std::string("debug_overlap: ") + hipGetErrorString(err));
         return VMM_BA_ERR_HIP;
     }
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 8; ++i)
         ms[i] = acc[i] / reps;
     return VMM_BA_OK;
 }

@@ -186,9 +186,10 @@ class BundleAdjuster:
 
     def debug_overlap(self, reps=10):
         """ms of: rank-k update + sum alone, factorisation + solves alone, both back to back, both at once on two streams."""
-        out = np.zeros(5)
+        out = np.zeros(8)
         _lib.check(_lib.lib().vmm_ba_debug_overlap(self._h, int(reps), _ptr(out)))
-        return dict(zip(("syrk_ms", "cholesky_ms", "sequential_ms", "concurrent_ms", "cholesky_in_concurrent_ms"), out.tolist()))
+        return dict(zip(("syrk_ms", "cholesky_ms", "sequential_ms", "concurrent_ms", "cholesky_in_concurrent_ms",
+                         "syrk_in_concurrent_ms", "concurrent_syrk_first_ms", "cholesky_in_concurrent_syrk_first_ms"), out.tolist()))
 
     def time_kernels(self, options=None, reps=5):
         o = options or default_options()
