@@ -323,7 +323,8 @@ def main():
                                     % (n_blk * (n_blk + 1) // 2 + n_blk, n_blk)) if dataflow else
                                    ("cholesky_solve = %d x k_chol_step + k_chol_dataflow on the last block columns + "
                                     "k_backsolve_chain" % max(n_blk - 34, 0)),
-                 "schur_syrk": "k_form_z<SPARSE> + k_schur_pairs" if kt.get("schur_sparse") else "k_syrk_streamk + k_reduce_partials",
+                 "schur_syrk": "k_form_z<SPARSE> + k_schur_pairs" if kt.get("schur_sparse") else
+                               ("k_syrk_wide" if kt.get("syrk_wide") else "k_syrk_streamk") + " + k_reduce_partials",
                  "eval_jacobian": "k_eval_both + k_reduce_pose", "eval_cost": "k_cost"}
         line["roofline"] = {"kernel": names.get(dom, dom), "bound": d["bound"], "achieved": d["achieved"],
                             "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": traffic.get(dom),

@@ -208,7 +208,7 @@ typedef struct vmm_ba_kernel_times {
     int32_t reduced_dim;     /* order of the dense reduced system (without padding) */
     int32_t elim_dim;        /* 6 * number of eliminated poses */
     int32_t schur_sparse;    /* 1: the reduced system is formed over co-observed (e, f) pairs only (compressed Z) */
-    int32_t reserved;
+    int32_t syrk_wide;       /* 1: the dense rank-k update runs k_syrk_wide (one 8-wave workgroup per CU; few tiles) */
     double schur_flops;      /* algorithmic flops of that formation: dense (n+1)(n+2) K; block-sparse 432 per pair of
                                 observations sharing an eliminated pose (lower triangle) + the right-hand side */
 } vmm_ba_kernel_times;

@@ -33,7 +33,7 @@ def traffic(names):
 groups = {
     "eval_jacobian": ["k_eval_both"],
     "eval_cost": ["k_cost<true, false>", "k_cost<true>"],
-    "schur_syrk": ["k_syrk_streamk"],
+    "schur_syrk": ["k_syrk_streamk", "k_syrk_wide"],
     "syrk_reduce": ["k_reduce_partials<true>"],
     "form_z": ["k_form_z"],
     "chol_step": ["k_chol_step"],

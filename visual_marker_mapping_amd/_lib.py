@@ -79,7 +79,7 @@ class KernelTimes(C.Structure):
                 ("form_z_ms", C.c_double), ("syrk_ms", C.c_double), ("cholesky_ms", C.c_double),
                 ("backsub_ms", C.c_double), ("lm_iteration_ms", C.c_double), ("n_obs", C.c_int64),
                 ("reduced_dim", C.c_int32), ("elim_dim", C.c_int32), ("schur_sparse", C.c_int32),
-                ("reserved", C.c_int32), ("schur_flops", C.c_double)]
+                ("syrk_wide", C.c_int32), ("schur_flops", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)

@@ -342,7 +342,8 @@ __device__ __forceinline__ void syrk_wide_item(const double* __restrict__ Z, con
             if (kt + h < kt1) {
                 const double* zr = Z + (int64_t)((kt + h) * kSyrkKT + lr) * ldz;
                 va[h] = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
-                vb[h] = *reinterpret_cast<const double4_t*>(zr + J0 + lc);   // diagonal tile: the same lines
+                if (!DIAG)   // a diagonal tile's two operands are the same columns of Z: one copy in the LDS
+                    vb[h] = *reinterpret_cast<const double4_t*>(zr + J0 + lc);
             }
         }
     };
@@ -350,7 +351,8 @@ __device__ __forceinline__ void syrk_wide_item(const double* __restrict__ Z, con
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             *reinterpret_cast<double4_t*>(&As[buf * kWideStage + (lr + 16 * h) * kSyrkRow + lc]) = va[h];
-            *reinterpret_cast<double4_t*>(&Bs[buf * kWideStage + (lr + 16 * h) * kSyrkRow + lc]) = vb[h];
+            if (!DIAG)
+                *reinterpret_cast<double4_t*>(&Bs[buf * kWideStage + (lr + 16 * h) * kSyrkRow + lc]) = vb[h];
         }
     };
     gload(kt0);
@@ -362,7 +364,7 @@ __device__ __forceinline__ void syrk_wide_item(const double* __restrict__ Z, con
         if (more)
             gload(kt + 2);   // the next stage's loads fly while this stage's MFMAs issue
         const double* Ap = As + buf * kWideStage + g * kSyrkKT * kSyrkRow;
-        const double* Bp = Bs + buf * kWideStage + g * kSyrkKT * kSyrkRow;
+        const double* Bp = DIAG ? Ap : Bs + buf * kWideStage + g * kSyrkKT * kSyrkRow;
 #pragma unroll
         for (int ks = 0; ks < kSyrkKT / 4; ++ks) {
             const int row = (ks * 4 + fk) * kSyrkRow;

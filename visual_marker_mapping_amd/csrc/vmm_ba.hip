@@ -235,6 +235,8 @@ static int make_syrk_plan(Engine& e, SyrkPlan& p, int n_row_blk, int n_col_blk, 
         }
     p.n_tiles = (int)bi.size();
     p.n_kt = k_pad / kKT;
+    if (const char* v = getenv("VMM_BA_DEBUG_SYRK_KT"))   // timing experiments only: a product over the first rows of Z
+        p.n_kt = std::max(2, std::min(atoi(v), p.n_kt));
     // two workgroups (72 KB of LDS each) per CU
     int hw = 0;
     hipDeviceProp_t prop;
@@ -2619,6 +2621,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     out->reduced_dim = e.n_red;
     out->elim_dim = e.k_dim;
     out->schur_sparse = e.sparse_schur ? 1 : 0;
+    out->syrk_wide = (!e.sparse_schur && e.syrk.wide) ? 1 : 0;
     out->schur_flops = e.schur_flops;
     // keep the caller's state: timing runs real iterations.  The RAW device buffers are saved and restored: through
     // vmm_ba_get_state / vmm_ba_set_state a point-landmark handle would get its tags back as exact rectangles rebuilt
