@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VMM_BA_ABI_VERSION 4
+#define VMM_BA_ABI_VERSION 5
 
 typedef struct vmm_ba_handle_s* vmm_ba_handle;
 
@@ -211,6 +211,9 @@ typedef struct vmm_ba_kernel_times {
     int32_t syrk_wide;       /* 1: the dense rank-k update runs k_syrk_wide (one 8-wave workgroup per CU; few tiles) */
     double schur_flops;      /* algorithmic flops of that formation: dense (n+1)(n+2) K; block-sparse 432 per pair of
                                 observations sharing an eliminated pose (lower triangle) + the right-hand side */
+    double chol_flops;       /* ABI 5.  Tree-ordered factor (vmm_ba_summary.tree_ordering > 0): flops of the Cholesky
+                                factorisation + the two triangular solves over the NON-ZERO 64 x 64 blocks of the factor
+                                (after fill); 0 for a dense factor, whose count is n^3 / 3 + 2 n^2 */
 } vmm_ba_kernel_times;
 
 const char* vmm_ba_last_error(void);

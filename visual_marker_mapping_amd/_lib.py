@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VMM_BA_LIB selects another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("VMM_BA_LIB") or os.path.join(_HERE, "libvmm_ba.so")
 
-ABI_VERSION = 4          # VMM_BA_ABI_VERSION of include/vmm_ba.h
+ABI_VERSION = 5          # VMM_BA_ABI_VERSION of include/vmm_ba.h
 RCCL_ID_BYTES = 128      # VMM_BA_RCCL_ID_BYTES
 PRECISION_F64, PRECISION_F32_ACCUM = 0, 1
 LANDMARK_TAG_POSES, LANDMARK_POINTS = 0, 1
@@ -79,7 +79,7 @@ class KernelTimes(C.Structure):
                 ("form_z_ms", C.c_double), ("syrk_ms", C.c_double), ("cholesky_ms", C.c_double),
                 ("backsub_ms", C.c_double), ("lm_iteration_ms", C.c_double), ("n_obs", C.c_int64),
                 ("reduced_dim", C.c_int32), ("elim_dim", C.c_int32), ("schur_sparse", C.c_int32),
-                ("syrk_wide", C.c_int32), ("schur_flops", C.c_double)]
+                ("syrk_wide", C.c_int32), ("schur_flops", C.c_double), ("chol_flops", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)

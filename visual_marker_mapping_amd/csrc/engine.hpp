@@ -205,6 +205,7 @@ struct Engine {
     std::vector<int32_t> nd_node_first_blk;   // tree ordering: first 64-row block of every node, in elimination order
     int n_row_items = 0;
     double schur_flops = 0.0;       // algorithmic flops of the reduced-system formation on the path in use
+    double chol_flops = 0.0;        // tree-ordered factor: flops over its non-zero blocks (0: dense factor)
     SyrkPlan syrk;                  // stream-K plan of S = Z^T Z
     double* S = nullptr;            // [ldz][ldz] reduced system (lower) + rhs row at n_pad
     double* S_packed = nullptr;     // world > 1: rows 0..n_pad of the lower triangle, packed, for the all-reduce

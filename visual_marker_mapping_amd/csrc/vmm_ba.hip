@@ -1762,6 +1762,20 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
                     nzw[(size_t)i * kDfMaskWords + w] = nzr[(size_t)i].w[w];
             if ((rc = dev_alloc(e, &e.chol_nz, nzw.size()))) return fail(rc);
             if ((rc = upload(e, e.chol_nz, nzw))) return fail(rc);
+            {
+                // what this factorisation computes: per block column the diagonal block (d^3 / 3), a triangular solve per
+                // non-zero block below it (d^3), a product per pair of them (2 d^3; d^3 on the diagonal), the right-hand
+                // side row with them (2 d^2 per block), and the back-substitution (2 d^2 per block)
+                const double d = (double)kNB;
+                double fl = 0.0;
+                for (int j2 = 0; j2 < e.n_blk; ++j2) {
+                    int nb = 0;
+                    for (int r = j2 + 1; r < e.n_blk; ++r)
+                        nb += nzr[(size_t)r].test(j2) ? 1 : 0;
+                    fl += d * d * d / 3.0 + nb * d * d * d + (double)nb * nb * d * d * d + 4.0 * (nb + 1) * d * d;
+                }
+                e.chol_flops = fl;
+            }
             // In which order does block column j take the panels it depends on?  In the order they are expected to be
             // finished, from the model of the kernel.
             std::vector<unsigned char> ord((size_t)e.n_blk * kDfMaxBlk, 0);
@@ -2623,6 +2637,7 @@ int vmm_ba_time_kernels(vmm_ba_handle h, const vmm_ba_options* opt, int reps, vm
     out->schur_sparse = e.sparse_schur ? 1 : 0;
     out->syrk_wide = (!e.sparse_schur && e.syrk.wide) ? 1 : 0;
     out->schur_flops = e.schur_flops;
+    out->chol_flops = e.chol_nz_on ? e.chol_flops : 0.0;
     // keep the caller's state: timing runs real iterations.  The RAW device buffers are saved and restored: through
     // vmm_ba_get_state / vmm_ba_set_state a point-landmark handle would get its tags back as exact rectangles rebuilt
     // from re-orthogonalised poses, not the optimised free corners it held.
