@@ -323,67 +323,96 @@ __device__ __forceinline__ void syrk_wide_item(const double* __restrict__ Z, con
     using T = WideTiles<DIAG, W>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int g = tid >> 8;             // which 16 rows of a stage this wave multiplies
-    const int lr = tid >> 5;            // 0..15 (+16 for the second half of a stage)
-    const int lc = (tid & 31) * 4;      // 0..124
+    const int g = tid >> 8;             // half 0: the even 16-row stages of the item's K range, half 1: the odd ones
+    const int t = tid & 255;
+    const int lr = t >> 5;              // 0..7 (+8 for the second eight rows of a stage)
+    const int lc = (t & 31) * 4;        // 0..124
     const int fk = lane >> 4, fi = lane & 15;
-    double* const As = smem;                     // [2][kWideStage]
-    double* const Bs = smem + 2 * kWideStage;    // [2][kWideStage]
+    // each half has its own pair of stage buffers, [buf][A | B][16][kSyrkRow], and loads its own stages
+    constexpr int kGStage = kSyrkKT * kSyrkRow;
+    double* const Ag = smem + g * 4 * kGStage;
     double4_t acc[T::NT];
 #pragma unroll
     for (int n = 0; n < T::NT; ++n)
         acc[n] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+    const int n0 = (kt1 - kt0 + 1) / 2;            // stages of half 0 (the longer one)
+    const int my_n = (kt1 - kt0 + 1 - g) / 2;      // stages of this half: kt0 + g, kt0 + g + 2, ...
     double4_t va[2], vb[2];
-    auto gload = [&](const int kt) {   // 16-row units kt, kt + 1; a unit at or behind kt1 is not this item's: zeros
+    auto gload = [&](const int i) {
+        const int kt = kt0 + 2 * i + g;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            va[h] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-            vb[h] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-            if (kt + h < kt1) {
-                const double* zr = Z + (int64_t)((kt + h) * kSyrkKT + lr) * ldz;
-                va[h] = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
-                if (!DIAG)   // a diagonal tile's two operands are the same columns of Z: one copy in the LDS
-                    vb[h] = *reinterpret_cast<const double4_t*>(zr + J0 + lc);
-            }
+            const double* zr = Z + (int64_t)(kt * kSyrkKT + lr + 8 * h) * ldz;
+            va[h] = *reinterpret_cast<const double4_t*>(zr + I0 + lc);
+            if (!DIAG)   // a diagonal tile's two operands are the same columns of Z: one copy in the LDS
+                vb[h] = *reinterpret_cast<const double4_t*>(zr + J0 + lc);
         }
     };
     auto lstore = [&](const int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            *reinterpret_cast<double4_t*>(&As[buf * kWideStage + (lr + 16 * h) * kSyrkRow + lc]) = va[h];
+            *reinterpret_cast<double4_t*>(&Ag[buf * 2 * kGStage + (lr + 8 * h) * kSyrkRow + lc]) = va[h];
             if (!DIAG)
-                *reinterpret_cast<double4_t*>(&Bs[buf * kWideStage + (lr + 16 * h) * kSyrkRow + lc]) = vb[h];
+                *reinterpret_cast<double4_t*>(&Ag[buf * 2 * kGStage + kGStage + (lr + 8 * h) * kSyrkRow + lc]) = vb[h];
         }
     };
-    gload(kt0);
-    lstore(0);
-    __syncthreads();
-    int buf = 0;
-    for (int kt = kt0; kt < kt1; kt += 2) {
-        const bool more = kt + 2 < kt1;
+    struct Frag {
+        double a[T::NA], b[T::NB];
+    };
+    auto read_ops = [&](const int buf, const int ks, Frag& f) {
+        const double* Ap = Ag + buf * 2 * kGStage;
+        const double* Bp = DIAG ? Ap : Ap + kGStage;
+        const int row = (ks * 4 + fk) * kSyrkRow;
+#pragma unroll
+        for (int i = 0; i < T::NA; ++i)
+            f.a[i] = Ap[row + 16 * T::arow(i) + fi];
+#pragma unroll
+        for (int j = 0; j < T::NB; ++j)
+            f.b[j] = Bp[row + 16 * T::bcol(j) + fi];
+    };
+    auto mfma_step = [&](const Frag& f) {
+#pragma unroll
+        for (int n = 0; n < T::NT; ++n)
+            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[T::ai(n)], f.b[T::bi(n)], acc[n], 0, 0, 0);
+    };
+    // The two halves run HALF A STAGE APART.  Left in step, all eight waves reach the end of a stage together: 64 KB of
+    // ds_write, the barrier, 32 KB of ds_read before anybody's first MFMA -- ~1200 idle cycles of the matrix pipe per
+    // 8192 (measured as 80 us in the loop for 70 us of MFMAs).  Here every barrier is a stage boundary for one half and
+    // the middle of a stage for the other, which has the operands of its next K step in registers and keeps the pipe of the
+    // SIMD they share busy while the first half writes, waits and reads.  Half 1 starts one barrier late and half 0 ends
+    // one barrier early; both execute 2 n0 + 2 barriers.
+    if (my_n > 0) {
+        gload(0);
+        lstore(0);
+    }
+    if (g == 1)
+        __syncthreads();
+    for (int i = 0; i < n0; ++i) {
+        __syncthreads();   // this half's stage i is in its buffer; the other half is in the middle of a stage
+        const bool have = i < my_n, more = i + 1 < my_n;
+        const int buf = i & 1;
+        Frag f0, f1, f2;
         if (more)
-            gload(kt + 2);   // the next stage's loads fly while this stage's MFMAs issue
-        const double* Ap = As + buf * kWideStage + g * kSyrkKT * kSyrkRow;
-        const double* Bp = DIAG ? Ap : Bs + buf * kWideStage + g * kSyrkKT * kSyrkRow;
-#pragma unroll
-        for (int ks = 0; ks < kSyrkKT / 4; ++ks) {
-            const int row = (ks * 4 + fk) * kSyrkRow;
-            double a[T::NA], b[T::NB];
-#pragma unroll
-            for (int i = 0; i < T::NA; ++i)
-                a[i] = Ap[row + 16 * T::arow(i) + fi];
-#pragma unroll
-            for (int j = 0; j < T::NB; ++j)
-                b[j] = Bp[row + 16 * T::bcol(j) + fi];
-#pragma unroll
-            for (int n = 0; n < T::NT; ++n)
-                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T::ai(n)], b[T::bi(n)], acc[n], 0, 0, 0);
+            gload(i + 1);   // the next stage's loads fly while this stage's MFMAs issue
+        if (have) {
+            read_ops(buf, 0, f0);
+            read_ops(buf, 1, f1);
+            mfma_step(f0);
+            read_ops(buf, 2, f2);   // in registers before the barrier: the first MFMAs behind it do not wait for the LDS
+            mfma_step(f1);
+        }
+        __syncthreads();   // the middle of this half's stage; a stage boundary of the other half
+        if (have) {
+            mfma_step(f2);
+            read_ops(buf, 3, f0);
+            mfma_step(f0);
         }
         if (more)
             lstore(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
     }
+    if (g == 0)
+        __syncthreads();
+    __syncthreads();   // every MFMA operand is read: the stage buffers are dead
     // The two halves exchange half of their accumulators through the LDS (dead now: the loop ends with a barrier); each
     // then holds the sums of half of the wave's MFMA tiles (own + other: the same bits either way) and stores those.
     constexpr int H = T::NT / 2;
