@@ -140,6 +140,26 @@ def test_cholesky_fallback_paths(eng, monkeypatch, env):
         np.testing.assert_array_equal(x, x2)
 
 
+@pytest.mark.parametrize("n", [1200, 2048, 3136])
+def test_complete_panels_read_as_plain_blocks_give_the_same_bits(eng, monkeypatch, n):
+    """k_chol_dataflow_bulk (VMM_BA_DF_BULK=1; the tree-ordered kernel always works this way): a workgroup that gets to a
+    panel when it is complete reads the producer's compact copy instead of sweeping granules -- at 19 blocks, where every
+    workgroup is resident and tracks production, at 32 and at 49 (the 34-column tail).  Same values, same order of
+    operations: the solution has the same bits as with the granule-only kernel."""
+    rng = np.random.default_rng(31)
+    B = rng.standard_normal((n, n))
+    A = B @ B.T + n * np.eye(n)
+    b = rng.standard_normal(n)
+    monkeypatch.setenv("VMM_BA_DF_BULK", "0")
+    x0, info0 = eng.dense_spd_solve(A, b)
+    monkeypatch.setenv("VMM_BA_DF_BULK", "1")
+    x1, info1 = eng.dense_spd_solve(A, b)
+    assert info0 == 0 and info1 == 0
+    np.testing.assert_array_equal(x0, x1)
+    ref = np.linalg.solve(A, b)
+    np.testing.assert_allclose(x1, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("n", [1408, 2048, 3072, 3136, 6000])
 def test_cholesky_large_orders(eng, n):
     """22 to 48 blocks (1408, 2048, 3072): k_chol_dataflow with more workgroups than compute units (275 to 1224; only a

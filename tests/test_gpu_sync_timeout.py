@@ -144,8 +144,11 @@ def test_give_up_of_a_single_workgroup_is_reported(monkeypatch, order):
     the abort word -- or not at all: with a tree ordering of two walls that share no image the last block column of the
     factor does not depend on the other wall's columns, and until round 3 only that column's workgroup reported give-ups
     (ADVICE round 3).  Whichever workgroup it is: the pass is redone and the trajectory is the undisturbed one."""
+    import os
     from visual_marker_mapping_amd import engine as eng
     from visual_marker_mapping_amd.synthetic import make_scene
+    if os.environ.get("VMM_BA_NO_DATAFLOW") == "1":   # (the forced-path runs of the whole suite, DESIGN.md section 6)
+        pytest.skip("the one-launch factorisation is switched off by the environment: no workgroup of it can give up")
     s = _two_clusters(make_scene(2, n_cams=300, n_tags=200, neighbors_min=6, neighbors_max=10))
     monkeypatch.setenv("VMM_BA_ORDER", order)
     monkeypatch.setenv("VMM_BA_SCHUR", "sparse")

@@ -218,6 +218,8 @@ struct Engine {
     unsigned long long* gran = nullptr;   // [2 * ld] {epoch, 32 value bits} granules of the chain's hand-offs
     bool no_chain = false;          // VMM_BA_NO_CHAIN=1: per-block back-substitution kernels
     unsigned long long* df_gran = nullptr;   // published 64x8 slices of the dataflow factorisation (<= 21 blocks)
+    double* df_compact = nullptr;            // the same blocks once they are COMPLETE, as plain doubles [slot][column][row]
+    unsigned* df_done = nullptr;             // [slot] == factorisation epoch: the block's compact copy is written
     bool no_dataflow = false;       // VMM_BA_NO_DATAFLOW=1: one k_chol_step launch per block column
     // debugging: VMM_BA_DEBUG_SPIN_LIMIT=<polls> [VMM_BA_DEBUG_SPIN_KERNEL=df|chain|both] [VMM_BA_DEBUG_SPIN_ONCE=1]
     // force spin give-ups in the one-launch factorisation / back-substitution (tests/test_gpu_edge_cases.py)

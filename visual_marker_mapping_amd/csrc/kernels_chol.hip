@@ -1523,6 +1523,8 @@ struct DfArgs {
                                     // non-zero blocks below the diagonal of a column (the right-hand side row last), then the
                                     // diagonal-only workgroup
     const int32_t* slot;            // with nz: [n_blk][n_blk + 1] slot of block (k, rb)'s slices in G, -1: structurally zero
+    double* Gc;                     // BULK kernels: [slot][64 columns][64 rows] the block once more, as plain doubles, written when
+    unsigned* done;                 // the workgroup is finished; done[slot] == epoch says so (release / acquire, agent scope)
 };
 
 
@@ -1826,11 +1828,13 @@ __device__ __forceinline__ bool slice_valid(const SliceRegs& g, const unsigned e
 // granule first
 __device__ __forceinline__ bool wait_slice(const unsigned long long* sl, const int lane, const unsigned epoch,
                                            const unsigned* abort_word, const bool direct, SliceRegs& g,
-                                           const unsigned kDfSpinLimit)
+                                           const unsigned kDfSpinLimit, bool* spun = nullptr)
 {
     for (unsigned n = 0;;) {
         if (kDfSpinLimit != 1u && __all(slice_valid(g, epoch)))   // a limit of 1 (debugging) gives up even on valid data
             return true;
+        if (spun)
+            *spun = true;   // the first look came back stale: this slice was not there yet
         if (!direct) {
             for (;;) {
                 const unsigned long long pv
@@ -1866,11 +1870,13 @@ __device__ __forceinline__ bool wait_slice(const unsigned long long* sl, const i
 // predecessor, and each block column started 2.3 us behind the last slice of the previous one, 3 us with shorter rounds.)
 __device__ __forceinline__ bool wait_slice_pair(const unsigned long long* sl, const unsigned long long* sl_next, const int lane,
                                                 const unsigned epoch, const unsigned* abort_word, SliceRegs& g, SliceRegs& gn,
-                                                const unsigned kDfSpinLimit)
+                                                const unsigned kDfSpinLimit, bool* spun = nullptr)
 {
     for (unsigned n = 0;;) {
         if (kDfSpinLimit != 1u && __all(slice_valid(g, epoch)))   // a limit of 1 (debugging) gives up even on valid data
             return true;
+        if (spun)
+            *spun = true;
         if (++n >= kDfSpinLimit)
             return false;
         if ((n & 63u) == 63u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch)
@@ -1896,11 +1902,13 @@ struct SliceMap {
     unsigned long long* G;
     int n_blk;
     const int32_t* slot;   // tree orderings: [n_blk][n_blk + 1] slot of block (k, rb), only the non-zero blocks have one
+    __device__ __forceinline__ int64_t index(int k, int rb) const
+    {
+        return slot ? (int64_t)slot[k * (n_blk + 1) + rb] : (int64_t)k * n_blk - (int64_t)k * (k - 1) / 2 + (rb - k - 1);
+    }
     __device__ __forceinline__ unsigned long long* at(int k, int rb, int r) const
     {
-        const int64_t base = slot ? (int64_t)slot[k * (n_blk + 1) + rb]
-                                  : (int64_t)k * n_blk - (int64_t)k * (k - 1) / 2 + (rb - k - 1);
-        return G + (base * 8 + r) * kDfSlice;
+        return G + (index(k, rb) * 8 + r) * kDfSlice;
     }
 };
 
@@ -2051,7 +2059,13 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
 
 // TREE: the factor has a block structure (DfArgs::nz, tree orderings): only the panels this block column depends on are
 // consumed, in DfArgs::order.  !TREE is the dense kernel: panels 0 .. j-1 in ascending order.
-template <bool HAS_T, bool TREE>
+// BULK: panels that are COMPLETE when this workgroup gets to them -- it works off a backlog: a separator column of a tree
+// ordering, a late block column of a system with more workgroups than compute units -- are read from the producers' compact
+// copies (DfArgs::Gc: plain doubles behind a completion word) instead of swept as granules: half the bytes and half the
+// loads of a look, no validity test, two slices per register set, requested across panel boundaries.  A panel still in
+// production is tracked through its granules as before; once a look has come back stale the workgroup has caught up
+// with production and stops asking for completion words.  !BULK is the kernel of round 4, instruction for instruction.
+template <bool HAS_T, bool TREE, bool BULK>
 __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const int lane, const int j, const int R,
                                            const Lds& m, const SliceMap& sm, const unsigned epoch, int* s_timeout, bool& ok)
 {
@@ -2116,9 +2130,10 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
                     const bool next_too = (it & 7) != 7;
                     unsigned long long* const sl = pi.base + (it & 7) * kDfSlice;
                     got = wait_slice_pair(sl, next_too ? sl + kDfSlice : nullptr, lane, epoch,
-                                          a.abort_word, g, gn, a.spin_limit);
+                                          a.abort_word, g, gn, a.spin_limit, nullptr);
                 } else if (have) {
-                    got = wait_slice(pi.base + (it & 7) * kDfSlice, lane, epoch, a.abort_word, false, g, a.spin_limit);
+                    got = wait_slice(pi.base + (it & 7) * kDfSlice, lane, epoch, a.abort_word, false, g, a.spin_limit,
+                                     nullptr);
                 }
 #ifdef VMM_STAMPS
                 if (m.stamp_j >= 0 && w == 0 && lane == 0 && it >= n_it - 2)
@@ -2146,13 +2161,99 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
                 g_df_stamps[m.stamp_j][80 + (it - (n_it - 8))] = __builtin_amdgcn_s_memrealtime();
 #endif
         };
-        request(0, ga);
-        request(1, gb);
-        for (int it = 0; it < n_it; it += 2) {
-            consume(it, ga, gb);
-            request(it + 2, ga);   // requested while the workers apply slice it
-            consume(it + 1, gb, ga);
-            request(it + 3, gb);
+        if constexpr (!BULK) {
+            request(0, ga);
+            request(1, gb);
+            for (int it = 0; it < n_it; it += 2) {
+                consume(it, ga, gb);
+                request(it + 2, ga);   // requested while the workers apply slice it
+                consume(it + 1, gb, ga);
+                request(it + 3, gb);
+            }
+        } else {
+            const int n_pan = n_it >> 3;
+            // one register set = two slices of a compact copy: lo[q] = column q of slice 2p, hi[q] = of slice 2p + 1
+            auto issue_pair = [&](const double* cb, const int p, SliceRegs& g) {
+                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(cb) + p * 1024 + lane;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    g.lo[q] = __hip_atomic_load(src + q * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    g.hi[q] = __hip_atomic_load(src + 512 + q * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            };
+            auto stage = [&](const int it, const unsigned long long (&v)[8]) {
+                double* X = m.Xs + (it & 1) * 2 * kDfXs + (w == 0 ? 0 : kDfXs);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    X[q * kLdsRow + lane] = __longlong_as_double((long long)v[q]);
+                __syncthreads();
+            };
+            // Is block (k, my_rb)'s compact copy written?  The completion word of a panel is requested one panel ahead (at the
+            // start of the panel in front of it), so that looking at it never waits: a panel that completes later than that is
+            // taken through its granules like one that is still in production.
+            auto flag_of = [&](const int pos, const double*& cb) -> unsigned {
+                cb = nullptr;
+                if (!sweeper || pos >= n_pan)
+                    return epoch + 1u;
+                const PanelInfo pi = panel_at(8 * pos);
+                if (!pi.has)
+                    return epoch + 1u;
+                const int64_t si = sm.index(pi.k, my_rb);
+                cb = a.Gc + si * 4096;
+                return __hip_atomic_load(a.done + si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            bool pre = false;               // the coming panel's first two pairs are already in ga / gb
+            const double* cb_cur = nullptr;
+            const double* cb_next = nullptr;
+            unsigned fl_next = flag_of(0, cb_next);
+            for (int pos = 0; pos < n_pan; ++pos) {
+                const int it0 = 8 * pos;
+                const unsigned fl = fl_next;
+                cb_cur = cb_next;
+                fl_next = flag_of(pos + 1, cb_next);   // on its way while this panel is applied
+                const bool bulk = pre || fl == epoch;
+                if (bulk) {
+                    if (!pre) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        issue_pair(cb_cur, 0, ga);
+                        issue_pair(cb_cur, 1, gb);
+                    }
+                    pre = false;
+                    stage(it0 + 0, ga.lo);
+                    stage(it0 + 1, ga.hi);
+                    issue_pair(cb_cur, 2, ga);
+                    stage(it0 + 2, gb.lo);
+                    stage(it0 + 3, gb.hi);
+                    issue_pair(cb_cur, 3, gb);
+                    stage(it0 + 4, ga.lo);
+                    stage(it0 + 5, ga.hi);
+                    const bool nbulk = fl_next == epoch;   // (requested eight slices ago)
+                    if (nbulk) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        issue_pair(cb_next, 0, ga);
+                    }
+                    stage(it0 + 6, gb.lo);
+                    stage(it0 + 7, gb.hi);
+                    if (nbulk) {
+                        issue_pair(cb_next, 1, gb);
+                        pre = true;
+                    }
+                } else {
+                    // granules: the panel is in production, structurally zero for my block row (zeros are staged), or this
+                    // wave only keeps the barriers
+                    request(it0, ga);
+                    request(it0 + 1, gb);
+#pragma unroll 1
+                    for (int it = it0; it < it0 + 8; it += 2) {
+                        consume(it, ga, gb);
+                        if (it + 2 < it0 + 8)
+                            request(it + 2, ga);
+                        consume(it + 1, gb, ga);
+                        if (it + 3 < it0 + 8)
+                            request(it + 3, gb);
+                    }
+                }
+            }
         }
     }
 #ifdef VMM_STAMPS
@@ -2294,7 +2395,7 @@ __device__ __forceinline__ void report_give_up(const DfArgs& a, const unsigned e
         raise_sync_timeout(a.ctl, 1);
 }
 
-template <bool HAS_T, bool TREE>
+template <bool HAS_T, bool TREE, bool BULK>
 __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, double* smem)
 {
     const int tid = threadIdx.x;
@@ -2336,7 +2437,7 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     __syncthreads();   // s_timeout
     bool ok = true;
     if (w < 2)
-        pivot_path<HAS_T, TREE>(a, w, lane, j, R, m, sm, epoch, &s_timeout, ok);
+        pivot_path<HAS_T, TREE, BULK>(a, w, lane, j, R, m, sm, epoch, &s_timeout, ok);
     else if (w == 2)
         worker_path<0, HAS_T, TREE>(a, lane, j, R, m);
     else
@@ -2369,6 +2470,20 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
             *reinterpret_cast<double2*>(a.S + (int64_t)(R0 + rr) * ld + K0 + c)
                 = make_double2(m.RA[rr * kLd + c], m.RA[rr * kLd + c + 1]);
     }
+    if (BULK) {
+        // the block once more for the workgroups that get to this panel when it is long complete: [column][row], what a
+        // consumer stages slice by slice (the granules carried the same values), then the completion word -- every thread's
+        // stores made visible (release at agent scope), then one thread says so
+        double* cb = a.Gc + sm.index(j, R) * 4096;
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int c = idx >> 6, rr = idx & 63;
+            cb[idx] = m.RA[rr * kLd + c];
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(a.done + sm.index(j, R), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (j == n_blk - 1 && tid == 0 && !ok)
         a.ctl->lin_fail = 1;   // (with a give-up the result is NaN-poisoned and `ok` says nothing: the pass is redone anyway)
     report_give_up(a, epoch, s_timeout);
@@ -2376,7 +2491,7 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
 
 } // namespace df2
 
-template <bool TREE>
+template <bool TREE, bool BULK>
 __device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
 {
     if (a.ctl->done)
@@ -2391,9 +2506,9 @@ __device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
         // only the non-zero blocks of the factor have a workgroup (listed panel-major by the host)
         const int j = a.wg[2 * (int)blockIdx.x], R = a.wg[2 * (int)blockIdx.x + 1];
         if (R > j)
-            df2::role<true, TREE>(a, j, R, smem);
+            df2::role<true, TREE, BULK>(a, j, R, smem);
         else
-            df2::role<false, TREE>(a, j, j, smem);
+            df2::role<false, TREE, BULK>(a, j, j, smem);
         return;
     }
     int b = (int)blockIdx.x, j = 0;
@@ -2406,20 +2521,28 @@ __device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
     if (j >= a.n_blk)
         return;
     if (b < a.n_blk - j)
-        df2::role<true, TREE>(a, j, j + 1 + b, smem);
+        df2::role<true, TREE, BULK>(a, j, j + 1 + b, smem);
     else
-        df2::role<false, TREE>(a, j, j, smem);
+        df2::role<false, TREE, BULK>(a, j, j, smem);
 }
 
 __global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
 {
-    chol_dataflow_body<false>(a);
+    chol_dataflow_body<false, false>(a);
+}
+
+// the same launch with the compact-copy path of pivot_path (BULK) for dense systems: workgroups that are dispatched late (22 to
+// 48 block columns, the 34-column tail of a large system) read the panels that are complete by then from their compact
+// copies.  Not faster there (launch_dataflow), kept as the tested dense form of what the tree-ordered kernel uses
+__global__ __launch_bounds__(256) void k_chol_dataflow_bulk(DfArgs a)
+{
+    chol_dataflow_body<false, true>(a);
 }
 
 // the same launch for a factor with a block structure (DfArgs::nz / order: tree orderings of the kept family)
 __global__ __launch_bounds__(256) void k_chol_dataflow_tree(DfArgs a)
 {
-    chol_dataflow_body<true>(a);
+    chol_dataflow_body<true, true>(a);
 }
 
 // One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their own column
@@ -2615,8 +2738,19 @@ static void launch_dataflow(Engine& e, double* S, int n_pad, int ld, LmCtl* ctl,
     a.order = a.nz ? e.chol_order : nullptr;
     a.wg = a.nz ? e.df_wg : nullptr;
     a.slot = a.nz ? e.df_slot : nullptr;
+    a.Gc = e.df_compact;
+    a.done = e.df_done;
+    const char* const bulk_v = getenv("VMM_BA_DF_BULK");   // (read per launch: tests switch it within one process)
+    const int bulk_env = bulk_v ? atoi(bulk_v) : -1;
+    // Dense systems: measured (MI355X, us per factorisation, granules only / compact copies): 24 block columns 278 / 295,
+    // 30: 387 / 390, 38: 582 / 583, 47: 896 / 891, the 34-column tail at n = 6000: 3023 / 3041 -- a late workgroup there is
+    // bound by its two worker waves (26 MFMAs per slice each), not by its sweeps; so only on request (VMM_BA_DF_BULK=1, tested).
+    // Tree orderings (k_chol_dataflow_tree) always: 2000 x 1000 close-up 1004 -> 874 us, 500 x 200 close-up 205 -> 200.
+    const bool bulk = e.df_compact && e.df_done && bulk_env > 0;
     if (a.nz)
         hipLaunchKernelGGL(k_chol_dataflow_tree, dim3(e.n_df_wg), dim3(256), 0, e.stream, a);
+    else if (bulk)
+        hipLaunchKernelGGL(k_chol_dataflow_bulk, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
     else
         hipLaunchKernelGGL(k_chol_dataflow, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
 }
@@ -2692,6 +2826,7 @@ int preload_chol_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsolve_chain)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_backsolve_chain_tree)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow_bulk)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow_tree)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_step)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_inverse)) != hipSuccess;

@@ -1861,6 +1861,10 @@ int vmm_ba_create(const vmm_ba_problem* p, const vmm_ba_create_options* copt, vm
         const size_t slots = std::max(nd * (nd + 1) / 2, e.no_dataflow ? (size_t)0 : e.df_tree_slots);
         if (slots > 0 && (rc = dev_alloc(e, &e.df_gran, slots * 8 * 1024)))
             return fail(rc);
+        if (slots > 0 && (rc = dev_alloc(e, &e.df_compact, slots * 4096, false)))
+            return fail(rc);
+        if (slots > 0 && (rc = dev_alloc(e, &e.df_done, slots)))
+            return fail(rc);
     }
     if ((rc = dev_alloc(e, &e.yf, (size_t)e.ldz))) return fail(rc);
     if ((rc = dev_alloc(e, &e.step_comm, (size_t)7 * e.n_e + 1))) return fail(rc);
@@ -2490,6 +2494,10 @@ static int make_scratch(Engine& e, int device, int ld)
         const int nb = ld / kNB - 1;   // ld = n_pad + 64
         const size_t nd = e.no_dataflow ? 0 : (size_t)dataflow_blocks(nb, e.n_cu);
         if (nd > 0 && (rc = dev_alloc(e, &e.df_gran, nd * (nd + 1) / 2 * 8 * 1024)))
+            return rc;
+        if (nd > 0 && (rc = dev_alloc(e, &e.df_compact, nd * (nd + 1) / 2 * 4096, false)))
+            return rc;
+        if (nd > 0 && (rc = dev_alloc(e, &e.df_done, nd * (nd + 1) / 2)))
             return rc;
     }
     if ((rc = dev_alloc(e, &e.ctl, 1))) return rc;
