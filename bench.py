@@ -325,7 +325,9 @@ def main():
                                    ("cholesky_solve = %d x k_chol_step + k_chol_dataflow on the last block columns + "
                                     "k_backsolve_chain" % max(n_blk - 34, 0)),
                  "schur_syrk": "k_form_z<SPARSE> + k_schur_pairs" if kt.get("schur_sparse") else
-                               ("k_syrk_wide" if kt.get("syrk_wide") else "k_syrk_streamk") + " + k_reduce_partials",
+                               ("k_syrk_wide" if kt.get("syrk_wide") else "k_syrk_streamk")
+                               + " (the rank-k kernel alone: its partial-tile sum k_reduce_partials is a launch of its own, "
+                                 "9 us at 500 x 200, profiles/r04_kernel_stats_working.csv)",
                  "eval_jacobian": "k_eval_both + k_reduce_pose", "eval_cost": "k_cost"}
         line["roofline"] = {"kernel": names.get(dom, dom), "bound": d["bound"], "achieved": d["achieved"],
                             "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": traffic.get(dom),
