@@ -131,7 +131,13 @@ def _native_rccl_worker(rank, world, port, out, graph, cfg=1):
     import torch
     import torch.distributed as dist
     os.environ["VMM_BA_FORCE_COLLECTIVES"] = "1"
-    os.environ["VMM_BA_RCCL_GRAPH"] = graph
+    if graph == "vote":
+        # the rank votes "my capture of the collectives failed" (VMM_BA_DEBUG_CAPTURE_FAIL): the agreement all-reduce says
+        # "not everybody", every rank drops its graph and replays four graphs around eagerly enqueued collectives
+        os.environ["VMM_BA_RCCL_GRAPH"] = "1"
+        os.environ["VMM_BA_DEBUG_CAPTURE_FAIL"] = str(rank)
+    else:
+        os.environ["VMM_BA_RCCL_GRAPH"] = graph
     from visual_marker_mapping_amd import distributed as vd
     from visual_marker_mapping_amd import engine as eng
     from visual_marker_mapping_amd.synthetic import make_scene
@@ -160,7 +166,7 @@ def _native_rccl_worker(rank, world, port, out, graph, cfg=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph", ["1", "0"])
+@pytest.mark.parametrize("graph", ["1", "0", "vote"])
 def test_native_rccl_path_single_rank(tmp_path, graph):
     mp = pytest.importorskip("torch.multiprocessing")
     from visual_marker_mapping_amd import engine as eng

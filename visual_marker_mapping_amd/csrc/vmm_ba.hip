@@ -773,8 +773,14 @@ static int run_iteration(Engine& e, const vmm_ba_options& o)
                 // ncclAllReduce calls of one side would never complete.  So the ranks agree on "everybody captured".
                 bool all_ok = false;
                 const std::string why = rc ? g_err : std::string();
+                // VMM_BA_DEBUG_CAPTURE_FAIL=<rank>: that rank votes "my capture failed" although it did not -- the path of a
+                // rank whose RCCL refuses the capture, without such an RCCL (tests/test_gpu_distributed.py)
+                bool mine = rc == VMM_BA_OK;
+                if (const char* v = getenv("VMM_BA_DEBUG_CAPTURE_FAIL"))
+                    if (v[0] && atoi(v) == e.rank)
+                        mine = false;
                 int arc;
-                if ((arc = rccl_agree(e, rc == VMM_BA_OK, &all_ok)))
+                if ((arc = rccl_agree(e, mine, &all_ok)))
                     return arc;
                 if (!all_ok) {
                     // a collective that cannot be recorded (here or on another rank): graphs around eagerly
