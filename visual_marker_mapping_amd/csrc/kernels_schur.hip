@@ -296,9 +296,10 @@ __global__ __launch_bounds__(256, 2) void k_syrk_streamk(const LmCtl* ctl, const
 //
 // k_syrk_streamk fills the chip with two 4-wave workgroups per CU and nine K slices per tile: 495 partial tiles of
 // 128 KB, written in one burst at the end (13 us of a 104 us launch) and read back by k_reduce_partials.  Here the two
-// workgroups of a CU are one: waves 0-3 multiply rows 0-15 of every 32-row stage, waves 4-7 rows 16-31, and the two
-// halves add their accumulators through the LDS before the one partial tile of the workgroup is stored -- half the
-// partial tiles (3-5 per output tile), half the store burst, half of what the reduction reads.
+// workgroups of a CU are one: waves 0-3 multiply the even 16-row stages of the workgroup's K slice, waves 4-7 the odd ones
+// (each half with its own stage buffers, half a stage apart: syrk_wide_item), and the two halves add their accumulators
+// through the LDS before the one partial tile of the workgroup is stored -- half the partial tiles (3-5 per output tile),
+// half the store burst, half of what the reduction reads.
 // A diagonal tile needs only the 36 MFMA tiles on and below its diagonal: wave w of a half takes tile rows w and 7 - w of
 // the 8 x 8 grid (w + 1 and 8 - w tiles: nine each), instead of one 64 x 64 quadrant each with the upper one dead and the
 // lower one setting the pace; the host plan gives a diagonal tile 9/16 of the workgroups of an off-diagonal one.
