@@ -204,6 +204,14 @@ def test_tree_ordering_at_2000_x_1000(oracle, monkeypatch):
     tree, cam_t, tag_t, _, _ = _solve(s, 0, None, monkeypatch)
     assert tree["block_sparse"] == 1 and tree["tree_ordering"] >= 8 and tree["num_sync_timeouts"] == 0
     assert tree["termination_type"] == eng.CONVERGENCE
+    # the default at this size is the six-wave form of the kernel (two helper workers while earlier panels are applied,
+    # VMM_BA_DF_HELP): a tile sees the same MFMAs in the same order whoever issues them -- the four-wave form gives the same bits
+    monkeypatch.setenv("VMM_BA_DF_HELP", "0")
+    four, cam_4, tag_4, _, _ = _solve(s, 0, None, monkeypatch)
+    monkeypatch.delenv("VMM_BA_DF_HELP", raising=False)
+    assert four["iterations"] == tree["iterations"] and four["final_cost"] == tree["final_cost"]
+    np.testing.assert_array_equal(cam_4, cam_t)
+    np.testing.assert_array_equal(tag_4, tag_t)
     monkeypatch.setenv("VMM_BA_ORDER", "natural")
     nat, cam_n, tag_n, _, _ = _solve(s, 0, None, monkeypatch)
     assert nat["tree_ordering"] == 0 and nat["block_sparse"] == 1

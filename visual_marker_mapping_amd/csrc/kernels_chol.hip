@@ -2065,10 +2065,15 @@ __device__ __forceinline__ void pivot_round(const int w, const int lane, const L
 // loads of a look, no validity test, two slices per register set, requested across panel boundaries.  A panel still in
 // production is tracked through its granules as before; once a look has come back stale the workgroup has caught up
 // with production and stops asking for completion words.  !BULK is the kernel of round 4, instruction for instruction.
-template <bool HAS_T, bool TREE, bool BULK>
+// MODE bit 1 (HELP): the workgroup has six waves -- two more workers (waves 4, 5) on the pivot waves' SIMDs, which hold six of
+// each worker's thirteen tiles while the EARLIER panels are applied (the pivot waves only sweep then: loads and integer
+// work, nothing on the f64 pipe an MFMA of another wave would block) and hand them to the workers through the LDS right
+// before the last slice, where they end.  A tile sees the same MFMAs in the same order whoever issues them: the same bits.
+template <bool HAS_T, bool TREE, int MODE>
 __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const int lane, const int j, const int R,
                                            const Lds& m, const SliceMap& sm, const unsigned epoch, int* s_timeout, bool& ok)
 {
+    constexpr bool BULK = (MODE & 1) != 0, HELP = (MODE & 2) != 0;
     const int n_it = TREE ? 8 * df_num_panels(a, j) : 8 * j;   // a multiple of 8
     if (n_it > 0) {
         // Two slices are on their way at any time (two register sets): a slice read costs a round trip to the level all
@@ -2117,7 +2122,13 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
                     issue_slice(pi.base + (it & 7) * kDfSlice, lane, g);
             }
         };
+        // HELP: the helpers' tiles reach the workers behind one more barrier, right before the last slice
+        auto help_before = [&](const int it) {
+            if (HELP && it == n_it - 1)
+                __syncthreads();
+        };
         auto consume = [&](const int it, SliceRegs& g, SliceRegs& gn) {
+            help_before(it);
             const PanelInfo pi = sweeper ? panel_at(it) : PanelInfo{ it >> 3, 0, true, nullptr };
             const int k = pi.k;
             const bool have = pi.has;
@@ -2182,6 +2193,7 @@ __device__ __forceinline__ void pivot_path(const DfArgs& a, const int w, const i
                 }
             };
             auto stage = [&](const int it, const unsigned long long (&v)[8]) {
+                help_before(it);
                 double* X = m.Xs + (it & 1) * 2 * kDfXs + (w == 0 ? 0 : kDfXs);
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
@@ -2321,34 +2333,48 @@ __device__ __forceinline__ void worker_round(const int lane, double4_t (&acc)[13
     if (J0 == 16) DF_CY(52);
 }
 
-template <int WK, bool HAS_T, bool TREE>
+constexpr int kHelpSplit = 7;   // HELP: a worker keeps its tiles 0..6 while earlier panels are applied, its helper holds 7..12
+
+// one tile of a worker, straight from global memory in accumulator layout
+template <int WK, int I, bool HAS_T>
+__device__ __forceinline__ void load_tile(double4_t (&acc)[13], const double* __restrict__ S, const int ld, const int n_pad,
+                                          const int K0, const int R0, const int fr, const int fk)
+{
+    constexpr int ti = tile_i(WK, I), tj = tile_j(WK, I);
+    acc[I] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+    if constexpr (!is_t(WK, I)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[I][r] = S[(int64_t)(K0 + 16 * ti + fk + 4 * r) * ld + K0 + 16 * tj + fr];
+    } else if constexpr (HAS_T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = R0 + 16 * ti + fk + 4 * r;
+            const int grow = (row <= n_pad) ? row : n_pad;   // clamp: always in bounds
+            const double tv = S[(int64_t)grow * ld + K0 + 16 * tj + fr];
+            acc[I][r] = (row <= n_pad) ? tv : 0.0;
+        }
+    }
+}
+
+template <int WK, bool HAS_T, bool TREE, bool HELP = false>
 __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, const int j, const int R, const Lds& m)
 {
     const int fr = lane & 15, fk = lane >> 4;
     const int K0 = j * kNB, R0 = R * kNB;
     const int ld = a.ld, n_pad = a.n_pad;
     const double* __restrict__ S = a.S;
-    // accumulator tiles straight from global memory, in accumulator layout
+    const int n_it = TREE ? 8 * df_num_panels(a, j) : 8 * j;
+    // accumulator tiles straight from global memory, in accumulator layout (HELP: the helper's tiles arrive later, unless
+    // there is no earlier panel and hence no helper at work)
     double4_t acc[13];
     for_tiles([&](auto idx) {
         constexpr int I = decltype(idx)::value;
-        constexpr int ti = tile_i(WK, I), tj = tile_j(WK, I);
-        acc[I] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
-        if constexpr (!is_t(WK, I)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[I][r] = S[(int64_t)(K0 + 16 * ti + fk + 4 * r) * ld + K0 + 16 * tj + fr];
-        } else if constexpr (HAS_T) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = R0 + 16 * ti + fk + 4 * r;
-                const int grow = (row <= n_pad) ? row : n_pad;   // clamp: always in bounds
-                const double tv = S[(int64_t)grow * ld + K0 + 16 * tj + fr];
-                acc[I][r] = (row <= n_pad) ? tv : 0.0;
-            }
-        }
+        if (!HELP || I < kHelpSplit || n_it == 0)
+            load_tile<WK, I, HAS_T>(acc, S, ld, n_pad, K0, R0, fr, fk);
+        else
+            acc[I] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
     }, Seq13{});
-    const int n_it = TREE ? 8 * df_num_panels(a, j) : 8 * j;
     for (int it = 0; it + 1 < n_it; ++it) {
         const double* XJ = m.Xs + (it & 1) * 2 * kDfXs;
         const double* XR = XJ + kDfXs;
@@ -2358,7 +2384,7 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
             load_ops_slice<WK, HAS_T>(XJ, XR, fr, fk, o);
             for_tiles([&](auto idx) {
                 constexpr int I = decltype(idx)::value;
-                if constexpr (HAS_T || !is_t(WK, I))
+                if constexpr ((HAS_T || !is_t(WK, I)) && (!HELP || I < kHelpSplit))
                     mfma_tile<WK, I>(acc, o);
             }, Seq13{});
         }
@@ -2368,6 +2394,18 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
 #endif
     }
     if (n_it > 0) {
+        if (HELP) {
+            __syncthreads();   // the helper's tiles are in the LDS (the result tile's area, dead until the rounds)
+            const double* M = m.RA + WK * (13 - kHelpSplit) * 256;
+            for_tiles([&](auto idx) {
+                constexpr int I = decltype(idx)::value;
+                if constexpr (I >= kHelpSplit) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[I][r] = M[((I - kHelpSplit) * 4 + r) * 64 + lane];
+                }
+            }, Seq13{});
+        }
         const double* XJ = m.Xs + ((n_it - 1) & 1) * 2 * kDfXs;
         __syncthreads();   // the last slice is staged
         worker_round<WK, 0, HAS_T, true>(lane, acc, m, XJ, XJ + kDfXs);
@@ -2383,6 +2421,50 @@ __device__ __forceinline__ void worker_path(const DfArgs& a, const int lane, con
     worker_round<WK, 56, HAS_T>(lane, acc, m);
 }
 
+// HELP: waves 4 and 5.  Worker WK's tiles kHelpSplit..12 from the start of the workgroup until the earlier panels are
+// applied (all slices but the last one), then into the LDS for the worker, and out.
+template <int WK, bool HAS_T, bool TREE>
+__device__ __forceinline__ void helper_path(const DfArgs& a, const int lane, const int j, const int R, const Lds& m)
+{
+    const int n_it = TREE ? 8 * df_num_panels(a, j) : 8 * j;
+    if (n_it == 0)
+        return;   // no earlier panel: the workers hold all their tiles from the start
+    const int fr = lane & 15, fk = lane >> 4;
+    const int K0 = j * kNB, R0 = R * kNB;
+    double4_t acc[13];
+    for_tiles([&](auto idx) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (I >= kHelpSplit)
+            load_tile<WK, I, HAS_T>(acc, a.S, a.ld, a.n_pad, K0, R0, fr, fk);
+        else
+            acc[I] = (double4_t){ 0.0, 0.0, 0.0, 0.0 };
+    }, Seq13{});
+    for (int it = 0; it + 1 < n_it; ++it) {
+        const double* XJ = m.Xs + (it & 1) * 2 * kDfXs;
+        const double* XR = XJ + kDfXs;
+        __syncthreads();
+        if (WK == 0 || HAS_T) {
+            Ops o[2];
+            load_ops_slice<WK, HAS_T>(XJ, XR, fr, fk, o);
+            for_tiles([&](auto idx) {
+                constexpr int I = decltype(idx)::value;
+                if constexpr ((HAS_T || !is_t(WK, I)) && I >= kHelpSplit)
+                    mfma_tile<WK, I>(acc, o);
+            }, Seq13{});
+        }
+    }
+    double* M = m.RA + WK * (13 - kHelpSplit) * 256;
+    for_tiles([&](auto idx) {
+        constexpr int I = decltype(idx)::value;
+        if constexpr (I >= kHelpSplit) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                M[((I - kHelpSplit) * 4 + r) * 64 + lane] = acc[I][r];
+        }
+    }, Seq13{});
+    __syncthreads();   // (the workers read behind this barrier; a wave that has ended no longer counts for the later ones)
+}
+
 // A give-up anywhere is a synchronisation failure, not an indefinite matrix: the pass pauses (LmCtl::done = 2) and the host
 // redoes the factorisation without the dataflow.  EVERY workgroup reports for itself -- the one that gave up, and any that
 // ends after somebody raised the abort word.  (Until round 3 only the last block column's workgroup did, on the grounds that
@@ -2395,9 +2477,10 @@ __device__ __forceinline__ void report_give_up(const DfArgs& a, const unsigned e
         raise_sync_timeout(a.ctl, 1);
 }
 
-template <bool HAS_T, bool TREE, bool BULK>
+template <bool HAS_T, bool TREE, int MODE>
 __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, double* smem)
 {
+    constexpr bool BULK = (MODE & 1) != 0, HELP = (MODE & 2) != 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2437,11 +2520,18 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
     __syncthreads();   // s_timeout
     bool ok = true;
     if (w < 2)
-        pivot_path<HAS_T, TREE, BULK>(a, w, lane, j, R, m, sm, epoch, &s_timeout, ok);
+        pivot_path<HAS_T, TREE, MODE>(a, w, lane, j, R, m, sm, epoch, &s_timeout, ok);
     else if (w == 2)
-        worker_path<0, HAS_T, TREE>(a, lane, j, R, m);
-    else
-        worker_path<1, HAS_T, TREE>(a, lane, j, R, m);
+        worker_path<0, HAS_T, TREE, HELP>(a, lane, j, R, m);
+    else if (w == 3)
+        worker_path<1, HAS_T, TREE, HELP>(a, lane, j, R, m);
+    else {   // HELP only (six waves)
+        if (w == 4)
+            helper_path<0, HAS_T, TREE>(a, lane, j, R, m);
+        else
+            helper_path<1, HAS_T, TREE>(a, lane, j, R, m);
+        return;
+    }
     __syncthreads();   // the pivot waves store their rows of the result tile behind the last round's barrier
     // results for the kernels after this launch
     if (!HAS_T) {
@@ -2491,7 +2581,7 @@ __device__ __forceinline__ void role(const DfArgs& a, const int j, const int R, 
 
 } // namespace df2
 
-template <bool TREE, bool BULK>
+template <bool TREE, int MODE>
 __device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
 {
     if (a.ctl->done)
@@ -2506,9 +2596,9 @@ __device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
         // only the non-zero blocks of the factor have a workgroup (listed panel-major by the host)
         const int j = a.wg[2 * (int)blockIdx.x], R = a.wg[2 * (int)blockIdx.x + 1];
         if (R > j)
-            df2::role<true, TREE, BULK>(a, j, R, smem);
+            df2::role<true, TREE, MODE>(a, j, R, smem);
         else
-            df2::role<false, TREE, BULK>(a, j, j, smem);
+            df2::role<false, TREE, MODE>(a, j, j, smem);
         return;
     }
     int b = (int)blockIdx.x, j = 0;
@@ -2521,14 +2611,14 @@ __device__ __forceinline__ void chol_dataflow_body(DfArgs& a)
     if (j >= a.n_blk)
         return;
     if (b < a.n_blk - j)
-        df2::role<true, TREE, BULK>(a, j, j + 1 + b, smem);
+        df2::role<true, TREE, MODE>(a, j, j + 1 + b, smem);
     else
-        df2::role<false, TREE, BULK>(a, j, j, smem);
+        df2::role<false, TREE, MODE>(a, j, j, smem);
 }
 
 __global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
 {
-    chol_dataflow_body<false, false>(a);
+    chol_dataflow_body<false, 0>(a);
 }
 
 // the same launch with the compact-copy path of pivot_path (BULK) for dense systems: workgroups that are dispatched late (22 to
@@ -2536,13 +2626,19 @@ __global__ __launch_bounds__(256) void k_chol_dataflow(DfArgs a)
 // copies.  Not faster there (launch_dataflow), kept as the tested dense form of what the tree-ordered kernel uses
 __global__ __launch_bounds__(256) void k_chol_dataflow_bulk(DfArgs a)
 {
-    chol_dataflow_body<false, true>(a);
+    chol_dataflow_body<false, 1>(a);
 }
 
 // the same launch for a factor with a block structure (DfArgs::nz / order: tree orderings of the kept family)
 __global__ __launch_bounds__(256) void k_chol_dataflow_tree(DfArgs a)
 {
-    chol_dataflow_body<true, true>(a);
+    chol_dataflow_body<true, 1>(a);
+}
+
+// six waves per workgroup: two helper workers while earlier panels are applied (pivot_path, HELP)
+__global__ __launch_bounds__(384) void k_chol_dataflow_tree_help(DfArgs a)
+{
+    chol_dataflow_body<true, 3>(a);
 }
 
 // One launch per block column k: workgroups [0, n_panel) factor panel k (with the lazy update of their own column
@@ -2747,7 +2843,16 @@ static void launch_dataflow(Engine& e, double* S, int n_pad, int ld, LmCtl* ctl,
     // bound by its two worker waves (26 MFMAs per slice each), not by its sweeps; so only on request (VMM_BA_DF_BULK=1, tested).
     // Tree orderings (k_chol_dataflow_tree) always: 2000 x 1000 close-up 1004 -> 874 us, 500 x 200 close-up 205 -> 200.
     const bool bulk = e.df_compact && e.df_done && bulk_env > 0;
-    if (a.nz)
+    // Helper waves (six waves per workgroup, the same bits): measured (MI355X, factorisation + solve, four / six waves) --
+    // tree orderings: 2000 x 1000 close-up (109 block columns) 876 / 810 us, 500 x 200 close-up (22) 202 / 202, corridor
+    // 120 / 124; dense: 19 block columns 226 / 238, 24: 281 / 294, 30: 389 / 410, 38: 582 / 617, 47: 892 / 954, the 34-column
+    // tail at n = 6000 3042 / 3070.  So: large tree-ordered factors only (VMM_BA_DF_HELP=0 / 1 decides otherwise; the dense
+    // kernels were measured with an instantiation that is not kept).
+    const char* const help_v = getenv("VMM_BA_DF_HELP");
+    const bool help = help_v ? help_v[0] == '1' : a.n_blk >= 64;
+    if (a.nz && help)
+        hipLaunchKernelGGL(k_chol_dataflow_tree_help, dim3(e.n_df_wg), dim3(384), 0, e.stream, a);
+    else if (a.nz)
         hipLaunchKernelGGL(k_chol_dataflow_tree, dim3(e.n_df_wg), dim3(256), 0, e.stream, a);
     else if (bulk)
         hipLaunchKernelGGL(k_chol_dataflow_bulk, dim3(dataflow_workgroups(a.n_blk)), dim3(256), 0, e.stream, a);
@@ -2828,6 +2933,7 @@ int preload_chol_kernels()
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow_bulk)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow_tree)) != hipSuccess;
+    bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_dataflow_tree_help)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_step)) != hipSuccess;
     bad += hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&k_chol_inverse)) != hipSuccess;
     return bad;
